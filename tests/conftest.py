@@ -1,0 +1,51 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "image-captioning_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Return the fixture as a dict of torch tensors / numpy scalars."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def sub_sd(fx, prefix):
+    """state_dict stored under ``prefix`` (e.g. 'sd__') as torch tensors."""
+    return {k[len(prefix):]: torch.from_numpy(np.asarray(v)) for k, v in fx.items() if k.startswith(prefix)}
+
+
+def unpad(rows, fill=-1):
+    return [[int(t) for t in r if t != fill] for r in np.asarray(rows)]
+
+
+class Vocab:
+    """get_loader.Vocabulary protocol: ids 0-3 are <PAD>,<SOS>,<EOS>,<UNK>."""
+
+    def __init__(self, n):
+        self.itos = {0: "<PAD>", 1: "<SOS>", 2: "<EOS>", 3: "<UNK>"}
+        for i in range(4, n):
+            self.itos[i] = f"w{i}"
+        self.stoi = {v: k for k, v in self.itos.items()}
+
+    def __len__(self):
+        return len(self.itos)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
