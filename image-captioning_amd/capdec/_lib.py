@@ -1,0 +1,107 @@
+"""ctypes binding of libcapdec.so (the C ABI declared in include/capdec.h).
+
+There is no CPU fallback: if the library is missing or a tensor is not on a HIP device the call
+raises.  Build the library first with ``python image-captioning_amd/capdec/_build.py``.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcapdec.so")
+
+ABI_VERSION = 1
+GEMM_RELU = 1
+DECODE_NO_S1_SHORTCUT = 1
+
+
+class GemmGroup(Structure):
+    _fields_ = [("P", c_void_p), ("Q", c_void_p), ("C", c_void_p), ("bias_i", c_void_p), ("bias_j", c_void_p),
+                ("scale_j", c_void_p), ("shift_j", c_void_p), ("R", c_void_p),
+                ("ldp", c_int64), ("ldq", c_int64), ("ldci", c_int64), ("ldcj", c_int64), ("ldri", c_int64),
+                ("ldrj", c_int64), ("I", c_int32), ("J", c_int32)]
+
+
+class AttnW(Structure):
+    _fields_ = [(n, c_void_p) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo")]
+
+
+class TfLayer(Structure):
+    _fields_ = [("self_attn", AttnW), ("cross_attn", AttnW)] + \
+               [(n, c_void_p) for n in ("ff_w1", "ff_b1", "ff_w2", "ff_b2", "n1_g", "n1_b", "n2_g", "n2_b", "n3_g", "n3_b")]
+
+
+class TfModel(Structure):
+    _fields_ = [("E", c_int32), ("H", c_int32), ("L", c_int32), ("V", c_int32), ("max_pos", c_int32),
+                ("emb", c_void_p), ("pe", c_void_p), ("fc2_w", c_void_p), ("fc2_b", c_void_p),
+                ("layers", POINTER(TfLayer))]
+
+
+class RnnModel(Structure):
+    _fields_ = [("E", c_int32), ("Hd", c_int32), ("V", c_int32), ("emb", c_void_p), ("w_ih", c_void_p),
+                ("w_hh", c_void_p), ("b_ih", c_void_p), ("b_hh", c_void_p), ("fc2_w", c_void_p), ("fc2_b", c_void_p)]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    "capdec_abi_version": (c_int, []),
+    "capdec_strerror": (c_char_p, [c_int]),
+    "capdec_gemm": (c_int, [POINTER(GemmGroup), c_int, c_int, c_int, _P]),
+    "capdec_vocab_tiles": (c_int, [c_int]),
+    "capdec_vocab_argmax_partial": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "capdec_argmax_finalize": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
+    "capdec_vocab_lse_partial": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "capdec_nll_finalize": (c_int, [_P, _P, c_int, c_int, _P, c_int64, _P, _P, c_int, _P, c_int64, _P, _P, _P, _P]),
+    "capdec_embed_pe": (c_int, [_P, c_int, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "capdec_add_layernorm": (c_int, [_P, _P, c_int, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P]),
+    "capdec_attention": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64,
+                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P]),
+    "capdec_lstm_step": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P, _P]),
+    "capdec_bn_fold": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
+    "capdec_bn_train_forward": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "capdec_tf_decode_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int]),
+    "capdec_tf_greedy_decode": (c_int, [POINTER(TfModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t,
+                                        _P, _P, _P, _P]),
+    "capdec_tf_exact_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int]),
+    "capdec_tf_greedy_decode_exact": (c_int, [POINTER(TfModel), _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t,
+                                              _P, _P, _P]),
+    "capdec_tf_forward_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int]),
+    "capdec_tf_forward_logits": (c_int, [POINTER(TfModel), _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
+    "capdec_rnn_decode_workspace_bytes": (c_size_t, [POINTER(RnnModel), c_int, c_int]),
+    "capdec_rnn_greedy_decode": (c_int, [POINTER(RnnModel), _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcapdec.so once; raise loudly if it is missing or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libcapdec.so not found at {LIB_PATH}: the HIP kernels are the only implementation of this package "
+            "(no CPU fallback). Build them with `python image-captioning_amd/capdec/_build.py` (needs hipcc).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"libcapdec.so does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.capdec_abi_version() != ABI_VERSION:
+        raise RuntimeError("libcapdec.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().capdec_strerror(int(rc)).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")

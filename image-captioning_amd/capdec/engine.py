@@ -1,0 +1,164 @@
+"""Host side of the whole-loop greedy decoders: packs a module's parameters into the C structs,
+owns the workspace tensor, and resolves rows that generated <PAD> through the exact path.
+
+The decode loops themselves live in libcapdec.so (csrc/engine.hip); one C call enqueues every step.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AttnW, RnnModel, TfLayer, TfModel
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError("capdec: decoder parameters must be contiguous fp32 tensors on the GPU (HIP)")
+    return t.data_ptr()
+
+
+def _attn(m):
+    return AttnW(_p(m.W_q.weight), _p(m.W_q.bias), _p(m.W_k.weight), _p(m.W_k.bias), _p(m.W_v.weight),
+                 _p(m.W_v.bias), _p(m.W_o.weight), _p(m.W_o.bias))
+
+
+class TfModelRef:
+    """capdec_tf_model built from a DecoderTransformer; keeps the ctypes arrays alive."""
+
+    def __init__(self, dec):
+        L = len(dec.decoder_layers)
+        self.layers = (TfLayer * max(L, 1))()
+        for l, ly in enumerate(dec.decoder_layers):
+            c = self.layers[l]
+            c.self_attn = _attn(ly.self_attn)
+            c.cross_attn = _attn(ly.cross_attn)
+            c.ff_w1, c.ff_b1 = _p(ly.feed_forward.fc1.weight), _p(ly.feed_forward.fc1.bias)
+            c.ff_w2, c.ff_b2 = _p(ly.feed_forward.fc2.weight), _p(ly.feed_forward.fc2.bias)
+            c.n1_g, c.n1_b = _p(ly.norm1.weight), _p(ly.norm1.bias)
+            c.n2_g, c.n2_b = _p(ly.norm2.weight), _p(ly.norm2.bias)
+            c.n3_g, c.n3_b = _p(ly.norm3.weight), _p(ly.norm3.bias)
+        emb = dec.decoder_embedding.weight
+        pe = dec.positional_encoding.pe
+        self.V, self.E = emb.shape
+        self.H = dec.decoder_layers[0].self_attn.num_heads if L else dec.num_heads
+        self.L = L
+        self.max_pos = pe.shape[1]
+        self.c = TfModel(self.E, self.H, L, self.V, self.max_pos, _p(emb), _p(pe), _p(dec.fc2.weight),
+                         _p(dec.fc2.bias), ctypes.cast(self.layers, ctypes.POINTER(TfLayer)))
+        self.device = emb.device
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+
+
+def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=False, resolve_dirty=True):
+    """Greedy decode on the GPU.  enc [B,S,E] fp32.  Returns (ids int64 [B,max_length] padded with -1, lengths
+    int32 [B]) as CPU tensors, plus the number of rows that went through the exact path."""
+    lib = _lib.load()
+    if not enc.is_cuda or enc.dtype != torch.float32:
+        raise RuntimeError("capdec: enc must be an fp32 tensor on the GPU (HIP); there is no CPU path")
+    enc = enc.contiguous()
+    B, S, E = enc.shape
+    ref = TfModelRef(dec)
+    if E != ref.E:
+        raise RuntimeError(f"capdec: encoder width {E} != embed size {ref.E}")
+    dev = enc.device
+    if B == 0:
+        return torch.empty((0, max_length), dtype=torch.int64), torch.empty((0,), dtype=torch.int32), 0
+    out_ids = torch.empty((B, max_length), dtype=torch.int64, device=dev)
+    out_len = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        if exact:
+            _exact(lib, ref, enc, max_length, sos, eos, out_ids, out_len)
+            return out_ids.cpu(), out_len.cpu(), B
+        dirty = torch.empty((B,), dtype=torch.int32, device=dev)
+        nbytes = lib.capdec_tf_decode_workspace_bytes(ctypes.byref(ref.c), B, S, max_length)
+        if nbytes == 0 and B > 0:
+            raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
+        ws = _workspace(nbytes, dev)
+        flags = _lib.DECODE_NO_S1_SHORTCUT if no_s1_shortcut else 0
+        _lib.check(lib.capdec_tf_greedy_decode(ctypes.byref(ref.c), enc.data_ptr(), B, S, max_length, sos, eos, flags,
+                                               ws.data_ptr(), ws.numel(), out_ids.data_ptr(), out_len.data_ptr(),
+                                               dirty.data_ptr(), _stream()), "capdec_tf_greedy_decode")
+        ids_c, len_c, dirty_c = out_ids.cpu(), out_len.cpu(), dirty.cpu()   # the one host sync of the decode
+        n_dirty = 0
+        if resolve_dirty:
+            rows = torch.nonzero(dirty_c, as_tuple=False).flatten()
+            n_dirty = int(rows.numel())
+            if n_dirty:
+                # a generated <PAD> makes that position's activations depend on the current length
+                # (transformer.py:117-123: PAD masks the query row); redo those rows on the exact path
+                sub = enc.index_select(0, rows.to(dev)).contiguous()
+                ids2 = torch.empty((n_dirty, max_length), dtype=torch.int64, device=dev)
+                len2 = torch.empty((n_dirty,), dtype=torch.int32, device=dev)
+                _exact(lib, ref, sub, max_length, sos, eos, ids2, len2)
+                ids_c[rows] = ids2.cpu()
+                len_c[rows] = len2.cpu()
+    return ids_c, len_c, n_dirty
+
+
+def _exact(lib, ref, enc, max_length, sos, eos, out_ids, out_len):
+    B, S, _ = enc.shape
+    nbytes = lib.capdec_tf_exact_workspace_bytes(ctypes.byref(ref.c), B, S, max_length)
+    if nbytes == 0 and B > 0:
+        raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
+    ws = _workspace(nbytes, enc.device)
+    _lib.check(lib.capdec_tf_greedy_decode_exact(ctypes.byref(ref.c), enc.data_ptr(), B, S, max_length, sos, eos,
+                                                 ws.data_ptr(), ws.numel(), out_ids.data_ptr(), out_len.data_ptr(),
+                                                 _stream()), "capdec_tf_greedy_decode_exact")
+
+
+def tf_forward_logits(dec, enc, ids, take_last=False):
+    """Inference-only teacher-forced forward (no autograd graph): logits [B,T,V] or [B,V]."""
+    lib = _lib.load()
+    if not enc.is_cuda or not ids.is_cuda:
+        raise RuntimeError("capdec: inputs must live on the GPU (HIP); there is no CPU path")
+    enc = enc.contiguous()
+    ids = ids.contiguous().to(torch.int64)
+    B, S, _ = enc.shape
+    T = ids.shape[1]
+    ref = TfModelRef(dec)
+    with torch.cuda.device(enc.device):
+        nbytes = lib.capdec_tf_forward_workspace_bytes(ctypes.byref(ref.c), B, S, T)
+        ws = _workspace(nbytes, enc.device)
+        shape = (B, ref.V) if take_last else (B, T, ref.V)
+        logits = torch.empty(shape, dtype=torch.float32, device=enc.device)
+        _lib.check(lib.capdec_tf_forward_logits(ctypes.byref(ref.c), enc.data_ptr(), ids.data_ptr(), B, S, T,
+                                                1 if take_last else 0, ws.data_ptr(), ws.numel(), logits.data_ptr(),
+                                                _stream()), "capdec_tf_forward_logits")
+    return logits
+
+
+def rnn_greedy_ids(rnn, x0, max_length, sos, eos):
+    """CNN-RNN greedy decode.  x0 [B,E] is the BatchNorm'ed image projection.  Returns CPU (ids, lengths)."""
+    lib = _lib.load()
+    if not x0.is_cuda or x0.dtype != torch.float32:
+        raise RuntimeError("capdec: x0 must be an fp32 tensor on the GPU (HIP); there is no CPU path")
+    x0 = x0.contiguous()
+    B, E = x0.shape
+    V = rnn.embed.weight.shape[0]
+    Hd = rnn.lstm.weight_hh_l0.shape[1]
+    m = RnnModel(E, Hd, V, _p(rnn.embed.weight), _p(rnn.lstm.weight_ih_l0), _p(rnn.lstm.weight_hh_l0),
+                 _p(rnn.lstm.bias_ih_l0), _p(rnn.lstm.bias_hh_l0), _p(rnn.fc2.weight), _p(rnn.fc2.bias))
+    dev = x0.device
+    if B == 0:
+        return torch.empty((0, max_length), dtype=torch.int64), torch.empty((0,), dtype=torch.int32)
+    out_ids = torch.empty((B, max_length), dtype=torch.int64, device=dev)
+    out_len = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = lib.capdec_rnn_decode_workspace_bytes(ctypes.byref(m), B, max_length)
+        ws = _workspace(nbytes, dev)
+        _lib.check(lib.capdec_rnn_greedy_decode(ctypes.byref(m), x0.data_ptr(), B, max_length, sos, eos, ws.data_ptr(),
+                                                ws.numel(), out_ids.data_ptr(), out_len.data_ptr(), _stream()),
+                   "capdec_rnn_greedy_decode")
+    return out_ids.cpu(), out_len.cpu()
+
+
+def ids_to_lists(ids, lengths):
+    ids = ids.tolist()
+    return [row[:n] for row, n in zip(ids, lengths.tolist())]

@@ -1,0 +1,232 @@
+"""Tensor-level wrappers over the C ABI (forward kernels).  Every tensor must live on a HIP device.
+
+PyTorch is used for device memory and the stream only; all arithmetic happens in libcapdec.so.
+"""
+from ctypes import byref
+
+import torch
+
+from . import _lib
+from ._lib import GemmGroup
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"capdec: {name} must be a tensor on the GPU (HIP); there is no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"capdec: {name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _row_stride(t, name):
+    """2-D view with unit column stride: returns (tensor, ld)."""
+    if t.dim() != 2 or t.stride(1) != 1 and t.shape[1] != 1:
+        raise RuntimeError(f"capdec: {name} must be 2-D with contiguous rows, got shape {tuple(t.shape)} "
+                           f"strides {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm_groups(groups, K, relu=False):
+    """groups: list of dicts with P,Q,C (2-D, row-contiguous) and optional bias_j,bias_i,scale_j,shift_j,R."""
+    lib = _lib.load()
+    n = len(groups)
+    arr = (GemmGroup * n)()
+    for g, d in zip(arr, groups):
+        P, Q, C = _chk(d["P"], name="P"), _chk(d["Q"], name="Q"), _chk(d["C"], name="C")
+        if P.shape[1] != K or Q.shape[1] != K:
+            raise RuntimeError(f"capdec gemm: K mismatch {tuple(P.shape)} {tuple(Q.shape)} K={K}")
+        if C.shape[0] != P.shape[0] or C.shape[1] != Q.shape[0]:
+            raise RuntimeError(f"capdec gemm: C shape {tuple(C.shape)} != ({P.shape[0]}, {Q.shape[0]})")
+        g.P, g.Q, g.C = P.data_ptr(), Q.data_ptr(), C.data_ptr()
+        g.ldp, g.ldq = _row_stride(P, "P"), _row_stride(Q, "Q")
+        g.ldci, g.ldcj = _row_stride(C, "C"), 1
+        g.I, g.J = P.shape[0], Q.shape[0]
+        for key, dim in (("bias_i", 0), ("bias_j", 1), ("scale_j", 1), ("shift_j", 1)):
+            t = d.get(key)
+            if t is not None:
+                _chk(t, name=key)
+                if t.numel() != C.shape[dim] or not t.is_contiguous():
+                    raise RuntimeError(f"capdec gemm: {key} has {t.numel()} elements, expected {C.shape[dim]}")
+            setattr(g, key, _ptr(t))
+        R = d.get("R")
+        if R is not None:
+            _chk(R, name="R")
+            if R.shape != C.shape:
+                raise RuntimeError("capdec gemm: residual shape mismatch")
+            g.R, g.ldri, g.ldrj = R.data_ptr(), _row_stride(R, "R"), 1
+    _lib.check(lib.capdec_gemm(arr, n, K, _lib.GEMM_RELU if relu else 0, _stream()), "capdec_gemm")
+
+
+def linear(x, W, b=None, relu=False, residual=None, scale=None, shift=None, out=None):
+    """y = x W^T + b with fused epilogue; x [M,K] (row stride free), W [N,K]."""
+    _chk(x, name="x")
+    _chk(W, name="W")
+    M, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    gemm_groups([dict(P=x, Q=W, C=out, bias_j=b, R=residual, scale_j=scale, shift_j=shift)], K, relu)
+    return out
+
+
+def embed_pe(ids, emb, pe, pos0=0):
+    """ids [B,T] int64/int32 -> [B*T, E] = emb[ids] + pe[pos0 : pos0+T]  (pe may be None)."""
+    lib = _lib.load()
+    if ids.dtype not in (torch.int64, torch.int32):
+        raise RuntimeError("capdec embed_pe: ids must be int64 or int32")
+    _chk(ids, ids.dtype, "ids")
+    _chk(emb, name="emb")
+    B, T = ids.shape
+    V, E = emb.shape
+    if ids.stride(1) != 1 and T > 1:
+        ids = ids.contiguous()
+    x = torch.empty((B * T, E), device=emb.device, dtype=torch.float32)
+    if pe is not None:
+        _chk(pe, name="pe")
+        if pe.dim() != 2 or pe.shape[1] != E or pe.shape[0] < pos0 + T or not pe.is_contiguous():
+            raise RuntimeError(f"capdec embed_pe: pe {tuple(pe.shape)} too short for {pos0 + T} positions")
+    _lib.check(lib.capdec_embed_pe(ids.data_ptr(), 1 if ids.dtype == torch.int32 else 0, ids.stride(0) if B > 1 else T,
+                                   emb.data_ptr(), _ptr(pe), pos0, B, T, E, V, x.data_ptr(), _stream()),
+               "capdec_embed_pe")
+    return x
+
+
+def add_layernorm(x, gamma, beta, add=None, add_div=1, eps=1e-5, out=None, want_stats=False):
+    lib = _lib.load()
+    _chk(x, name="x")
+    M, E = x.shape
+    if not x.is_contiguous():
+        raise RuntimeError("capdec add_layernorm: x must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    if add is not None:
+        _chk(add, name="add")
+        if not add.is_contiguous() or add.shape[-1] != E or add.numel() // E * add_div < M:
+            raise RuntimeError("capdec add_layernorm: add shape mismatch")
+    _lib.check(lib.capdec_add_layernorm(x.data_ptr(), _ptr(add), add_div, _chk(gamma).data_ptr(),
+                                        _chk(beta).data_ptr(), eps, M, E, out.data_ptr(), _ptr(mean), _ptr(rstd),
+                                        _stream()), "capdec_add_layernorm")
+    return (out, mean, rstd) if want_stats else out
+
+
+def attention(q, k, v, B, H, Tq, Tk, causal=False, ids32=None, out=None, want_lse=False):
+    """q [B*Tq, E], k/v [B*Tk, E] row-contiguous 2-D views (row stride free) -> out [B*Tq, E]."""
+    lib = _lib.load()
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, name=n)
+    E = q.shape[1]
+    dk = E // H
+    if out is None:
+        out = torch.empty((B * Tq, E), device=q.device, dtype=torch.float32)
+    lse = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32) if want_lse else None
+    ldid = 0
+    if ids32 is not None:
+        _chk(ids32, torch.int32, "ids32")
+        ldid = ids32.stride(0) if B > 1 else max(ids32.shape[1], Tq)
+    ldk, ldv = _row_stride(k, "k"), _row_stride(v, "v")
+    _lib.check(lib.capdec_attention(q.data_ptr(), _row_stride(q, "q"), k.data_ptr(), ldk, ldk * Tk, v.data_ptr(), ldv,
+                                    ldv * Tk, out.data_ptr(), _row_stride(out, "out"), B, H, Tq, Tk, dk,
+                                    1 if causal else 0, 0, _ptr(ids32), ldid, _ptr(lse), _stream()),
+               "capdec_attention")
+    return (out, lse) if want_lse else out
+
+
+def bn_fold(gamma, beta, running_mean, running_var, eps=1e-5):
+    lib = _lib.load()
+    C = gamma.numel()
+    scale = torch.empty(C, device=gamma.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    _lib.check(lib.capdec_bn_fold(_chk(gamma).data_ptr(), _chk(beta).data_ptr(), _chk(running_mean).data_ptr(),
+                                  _chk(running_var).data_ptr(), eps, C, scale.data_ptr(), shift.data_ptr(), _stream()),
+               "capdec_bn_fold")
+    return scale, shift
+
+
+def bn_train_forward(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    lib = _lib.load()
+    _chk(x, name="x")
+    if not x.is_contiguous():
+        raise RuntimeError("capdec bn_train_forward: x must be contiguous")
+    B, C = x.shape
+    if B < 2:
+        raise ValueError("Expected more than 1 value per channel when training")
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    _lib.check(lib.capdec_bn_train_forward(x.data_ptr(), _chk(gamma).data_ptr(), _chk(beta).data_ptr(), eps, momentum,
+                                           _ptr(running_mean), _ptr(running_var), B, C, y.data_ptr(), mean.data_ptr(),
+                                           rstd.data_ptr(), _stream()), "capdec_bn_train_forward")
+    return y, mean, rstd
+
+
+def lstm_step(x, h0, c0, w_ih, w_hh, b_ih, b_hh, want_gates=False, h_out=None):
+    """One fused LSTM step.  h_out (optional) is a [B,Hd] view with unit column stride to write h' into."""
+    lib = _lib.load()
+    _chk(x, name="x")
+    B, E = x.shape
+    Hd = w_hh.shape[1]
+    h1 = torch.empty((B, Hd), device=x.device, dtype=torch.float32) if h_out is None else _chk(h_out, name="h_out")
+    c1 = torch.empty((B, Hd), device=x.device, dtype=torch.float32)
+    gates = torch.empty((B, 4 * Hd), device=x.device, dtype=torch.float32) if want_gates else None
+    if c0 is not None and not c0.is_contiguous():
+        raise RuntimeError("capdec lstm_step: c0 must be contiguous")
+    _lib.check(lib.capdec_lstm_step(x.data_ptr(), _row_stride(x, "x"), _ptr(h0),
+                                    0 if h0 is None else _row_stride(h0, "h0"), _ptr(c0), _chk(w_ih).data_ptr(),
+                                    _chk(w_hh).data_ptr(), _chk(b_ih).data_ptr(), _chk(b_hh).data_ptr(), B, E, Hd,
+                                    h1.data_ptr(), _row_stride(h1, "h1"), c1.data_ptr(), _ptr(gates), _stream()),
+               "capdec_lstm_step")
+    return (h1, c1, gates) if want_gates else (h1, c1)
+
+
+def vocab_argmax(x, W, b):
+    """argmax_v (x W^T + b) per row without writing the logits; returns (idx int32 [M], val fp32 [M])."""
+    lib = _lib.load()
+    _chk(x, name="x")
+    M, K = x.shape
+    V = W.shape[0]
+    nt = lib.capdec_vocab_tiles(V)
+    pv = torch.empty((M, nt), device=x.device, dtype=torch.float32)
+    pi = torch.empty((M, nt), device=x.device, dtype=torch.int32)
+    _lib.check(lib.capdec_vocab_argmax_partial(x.data_ptr(), _row_stride(x, "x"), _chk(W).data_ptr(),
+                                               _chk(b).data_ptr(), M, V, K, pv.data_ptr(), pi.data_ptr(), _stream()),
+               "capdec_vocab_argmax_partial")
+    idx = torch.empty(M, device=x.device, dtype=torch.int32)
+    val = torch.empty(M, device=x.device, dtype=torch.float32)
+    _lib.check(lib.capdec_argmax_finalize(pv.data_ptr(), pi.data_ptr(), M, nt, idx.data_ptr(), val.data_ptr(),
+                                          _stream()), "capdec_argmax_finalize")
+    return idx, val
+
+
+def vocab_nll(x, W, b, targets, ignore_index=0):
+    """Fused projection + log-sum-exp + target pick.  Returns (lse [M], nll [M], sums [2] = (sum nll, n valid))."""
+    lib = _lib.load()
+    _chk(x, name="x")
+    _chk(targets, torch.int64, "targets")
+    M, K = x.shape
+    V = W.shape[0]
+    nt = lib.capdec_vocab_tiles(V)
+    pm = torch.empty((M, nt), device=x.device, dtype=torch.float32)
+    ps = torch.empty((M, nt), device=x.device, dtype=torch.float32)
+    _lib.check(lib.capdec_vocab_lse_partial(x.data_ptr(), _row_stride(x, "x"), _chk(W).data_ptr(), _chk(b).data_ptr(),
+                                            M, V, K, pm.data_ptr(), ps.data_ptr(), _stream()),
+               "capdec_vocab_lse_partial")
+    lse = torch.empty(M, device=x.device, dtype=torch.float32)
+    nll = torch.empty(M, device=x.device, dtype=torch.float32)
+    sums = torch.zeros(2, device=x.device, dtype=torch.float32)
+    _lib.check(lib.capdec_nll_finalize(pm.data_ptr(), ps.data_ptr(), M, nt, x.data_ptr(), _row_stride(x, "x"),
+                                       W.data_ptr(), b.data_ptr(), K, targets.contiguous().data_ptr(), ignore_index,
+                                       lse.data_ptr(), nll.data_ptr(), sums.data_ptr(), _stream()),
+               "capdec_nll_finalize")
+    return lse, nll, sums

@@ -1,0 +1,57 @@
+// Shared device/host helpers for libcapdec (gfx950 only: 64-lane wavefronts, fp32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/capdec.h"
+
+#define CAPDEC_WAVE 64
+
+#define CAPDEC_REQUIRE(cond)            \
+    do {                                \
+        if (!(cond)) return CAPDEC_EINVAL; \
+    } while (0)
+
+#define CAPDEC_LAUNCH_CHECK()                       \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+#define CAPDEC_TRY(expr)          \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+static inline bool capdec_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- wavefront (64-lane) reductions -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// arg-max with torch.argmax tie rule (lowest index wins)
+__device__ __forceinline__ void argmax_merge(float& v, int& i, float v2, int i2) {
+    if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float v2 = __shfl_xor(v, o, 64);
+        int i2 = __shfl_xor(i, o, 64);
+        argmax_merge(v, i, v2, i2);
+    }
+}
+
+// internal launchers shared between translation units (all return 0 / CAPDEC_E* / hipError_t)
+int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, hipStream_t s);

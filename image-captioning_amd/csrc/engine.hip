@@ -1,0 +1,455 @@
+// Whole-loop greedy decoders and the teacher-forced forward for gfx950.
+//
+// One host call enqueues every kernel of every decode step on the caller's stream; nothing here
+// synchronises the host or allocates.  Token ids, done flags and output lengths live on the device;
+// the arg-max of the vocabulary projection is fused into the projection (logits are never written)
+// and the kernel that picks the winner also writes the next step's input row (embedding + position).
+#include "common.h"
+#include <limits.h>
+#include <math.h>
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
+
+// bump allocator over the caller's workspace; with base == nullptr it only measures
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    template <typename T>
+    T* take(size_t n) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += up(n * sizeof(T));
+        return p;
+    }
+};
+
+// ---- bookkeeping kernels ------------------------------------------------------------------------
+__global__ void greedy_init_kernel(int32_t* tok, int64_t ldtok, int32_t* done, int64_t* out_ids, int32_t* out_len,
+                                   int32_t* dirty, int B, int max_len, int sos) {
+    const int n = B * max_len;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) out_ids[idx] = -1;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        tok[(int64_t)b * ldtok] = sos;
+        done[b] = 0;
+        out_len[b] = 0;
+        if (dirty) dirty[b] = 0;
+    }
+}
+
+// One wavefront per row: merge the per-tile arg-max winners, record the token exactly as the
+// reference's host loop does (transformer.py:155-171 / cnnrnn_model.py:90-106: a finished row keeps
+// feeding its prediction back but records nothing), and write the next step's input row.
+__global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
+                                                             int B, int ntiles, int t, int max_len, int eos,
+                                                             int32_t* tok, int64_t ldtok, int32_t* done,
+                                                             int64_t* out_ids, int32_t* out_len, int32_t* dirty,
+                                                             const float* __restrict__ emb,
+                                                             const float* __restrict__ pe, int E, int V,
+                                                             float* __restrict__ x_next) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    float v = -INFINITY;
+    int i = INT_MAX;
+    for (int n = lane; n < ntiles; n += 64) argmax_merge(v, i, pv[(int64_t)b * ntiles + n], pi[(int64_t)b * ntiles + n]);
+    wave_argmax(v, i);
+    if (i < 0 || i >= V) i = 0;   // all-NaN row: no finite winner
+    if (lane == 0) {
+        tok[(int64_t)b * ldtok + t + 1] = i;
+        if (!done[b]) {
+            if (i == eos) {
+                done[b] = 1;
+            } else {
+                const int n = out_len[b];
+                out_ids[(int64_t)b * max_len + n] = i;
+                out_len[b] = n + 1;
+                if (i == 0 && dirty) dirty[b] = 1;
+            }
+        }
+    }
+    if (x_next) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(emb + (int64_t)i * E);
+        const f32x4* pp = pe ? reinterpret_cast<const f32x4*>(pe + (int64_t)(t + 1) * E) : nullptr;
+        f32x4* dst = reinterpret_cast<f32x4*>(x_next + (int64_t)b * E);
+        for (int c = lane; c < E / 4; c += 64) {
+            f32x4 w = src[c];
+            if (pp) w += pp[c];
+            dst[c] = w;
+        }
+    }
+}
+
+int check_model(const capdec_tf_model* m) {
+    CAPDEC_REQUIRE(m && m->E >= 16 && m->E % 4 == 0 && m->H >= 1 && m->E % m->H == 0 && m->L >= 0 && m->V >= 1 &&
+                   m->max_pos >= 1);
+    const int dk = m->E / m->H;
+    CAPDEC_REQUIRE(dk == 16 || dk == 32 || dk == 64 || dk == 128 || dk == 256);
+    CAPDEC_REQUIRE(m->emb && m->pe && m->fc2_w && m->fc2_b && (m->L == 0 || m->layers));
+    return 0;
+}
+
+capdec_gemm_group linear_group(const float* x, int64_t ldx, int M, const float* W, const float* b, int N, float* C,
+                               int64_t ldc, const float* R = nullptr, int64_t ldr = 0) {
+    capdec_gemm_group g{};
+    g.P = x; g.Q = W; g.C = C; g.bias_j = b; g.R = R;
+    g.ldp = ldx; g.ldq = 0 /* set by caller */; g.ldci = ldc; g.ldcj = 1; g.ldri = ldr; g.ldrj = 1;
+    g.I = M; g.J = N;
+    return g;
+}
+
+// y = x W^T + b (+ R), W [N,K]
+int linear(const float* x, int64_t ldx, int M, const float* W, const float* b, int N, int K, float* C, int64_t ldc,
+           const float* R, int64_t ldr, int flags, hipStream_t s) {
+    capdec_gemm_group g = linear_group(x, ldx, M, W, b, N, C, ldc, R, ldr);
+    g.ldq = K;
+    return capdec_launch_gemm(&g, 1, K, flags, s);
+}
+
+// ---- cross-attention memory: K/V projections of the encoder rows, once per call -----------------
+int project_memory(const capdec_tf_model* m, const float* enc, int B, int S, float* ck, float* cv, hipStream_t s) {
+    const int E = m->E;
+    for (int l = 0; l < m->L; ++l) {
+        const capdec_attn_w& w = m->layers[l].cross_attn;
+        capdec_gemm_group g[2];
+        g[0] = linear_group(enc, E, B * S, w.wk, w.bk, E, ck + (size_t)l * B * S * E, E);
+        g[1] = linear_group(enc, E, B * S, w.wv, w.bv, E, cv + (size_t)l * B * S * E, E);
+        g[0].ldq = g[1].ldq = E;
+        CAPDEC_TRY(capdec_launch_gemm(g, 2, E, 0, s));
+    }
+    return 0;
+}
+
+// ---- decoder stack over a block of rows ------------------------------------------------------
+// Full-prefix form: X [B*T,E] in, X out (post-LN); every position of every sample is recomputed.
+struct FullBufs {
+    float *X, *Y, *X1, *X2, *Qb, *Kb, *Vb, *AO, *Hb;
+};
+
+int decoder_stack_full(const capdec_tf_model* m, const FullBufs& w, const float* ck, const float* cv, int B, int S,
+                       int T, const int32_t* tok, int64_t ldtok, hipStream_t s) {
+    const int E = m->E, H = m->H, dk = E / H, M = B * T;
+    void* vs = (void*)s;
+    for (int l = 0; l < m->L; ++l) {
+        const capdec_tf_layer& ly = m->layers[l];
+        capdec_gemm_group g[3];
+        g[0] = linear_group(w.X, E, M, ly.self_attn.wq, ly.self_attn.bq, E, w.Qb, E);
+        g[1] = linear_group(w.X, E, M, ly.self_attn.wk, ly.self_attn.bk, E, w.Kb, E);
+        g[2] = linear_group(w.X, E, M, ly.self_attn.wv, ly.self_attn.bv, E, w.Vb, E);
+        g[0].ldq = g[1].ldq = g[2].ldq = E;
+        CAPDEC_TRY(capdec_launch_gemm(g, 3, E, 0, s));
+        CAPDEC_TRY(capdec_attention(w.Qb, E, w.Kb, E, (int64_t)T * E, w.Vb, E, (int64_t)T * E, w.AO, E, B, H, T, T, dk,
+                                    1, 0, tok, ldtok, nullptr, vs));
+        CAPDEC_TRY(linear(w.AO, E, M, ly.self_attn.wo, ly.self_attn.bo, E, E, w.Y, E, w.X, E, 0, s));
+        CAPDEC_TRY(capdec_add_layernorm(w.Y, nullptr, 1, ly.n1_g, ly.n1_b, 1e-5f, M, E, w.X1, nullptr, nullptr, vs));
+        // cross attention over the S memory rows (never masked)
+        CAPDEC_TRY(linear(w.X1, E, M, ly.cross_attn.wq, ly.cross_attn.bq, E, E, w.Qb, E, nullptr, 0, 0, s));
+        CAPDEC_TRY(capdec_attention(w.Qb, E, ck + (size_t)l * B * S * E, E, (int64_t)S * E,
+                                    cv + (size_t)l * B * S * E, E, (int64_t)S * E, w.AO, E, B, H, T, S, dk, 0, 0,
+                                    nullptr, 0, nullptr, vs));
+        CAPDEC_TRY(linear(w.AO, E, M, ly.cross_attn.wo, ly.cross_attn.bo, E, E, w.Y, E, w.X1, E, 0, s));
+        CAPDEC_TRY(capdec_add_layernorm(w.Y, nullptr, 1, ly.n2_g, ly.n2_b, 1e-5f, M, E, w.X2, nullptr, nullptr, vs));
+        // feed forward, d_ff = E
+        CAPDEC_TRY(linear(w.X2, E, M, ly.ff_w1, ly.ff_b1, E, E, w.Hb, E, nullptr, 0, CAPDEC_GEMM_RELU, s));
+        CAPDEC_TRY(linear(w.Hb, E, M, ly.ff_w2, ly.ff_b2, E, E, w.Y, E, w.X2, E, 0, s));
+        CAPDEC_TRY(capdec_add_layernorm(w.Y, nullptr, 1, ly.n3_g, ly.n3_b, 1e-5f, M, E, w.X, nullptr, nullptr, vs));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// =================================================================================================
+// KV-cached greedy decode
+// =================================================================================================
+struct DecodeWs {
+    float *x, *y, *x1, *x2, *q, *ao, *hb;
+    float *kc, *vc;          // [L][B][max_len][E]
+    float *ck, *cv;          // [L][B*S][E]
+    float *cc;               // [L][B][E]  S == 1: the whole cross-attention block output per sample
+    float* pval; int32_t* pidx;
+    int32_t *tok, *done;
+};
+
+static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, void* base, DecodeWs* w) {
+    Carver c(base);
+    const size_t BE = (size_t)B * m->E;
+    DecodeWs d;
+    d.x = c.take<float>(BE); d.y = c.take<float>(BE); d.x1 = c.take<float>(BE); d.x2 = c.take<float>(BE);
+    d.q = c.take<float>(BE); d.ao = c.take<float>(BE); d.hb = c.take<float>(BE);
+    d.kc = c.take<float>((size_t)m->L * BE * max_len);
+    d.vc = c.take<float>((size_t)m->L * BE * max_len);
+    d.ck = c.take<float>((size_t)m->L * BE * S);
+    d.cv = c.take<float>((size_t)m->L * BE * S);
+    d.cc = c.take<float>((size_t)m->L * BE);
+    const size_t nt = (size_t)capdec_vocab_tiles(m->V);
+    d.pval = c.take<float>((size_t)B * nt);
+    d.pidx = c.take<int32_t>((size_t)B * nt);
+    d.tok = c.take<int32_t>((size_t)B * (max_len + 1));
+    d.done = c.take<int32_t>((size_t)B);
+    if (w) *w = d;
+    return c.off;
+}
+
+size_t capdec_tf_decode_workspace_bytes(const capdec_tf_model* m, int B, int S, int max_len) {
+    if (check_model(m) != 0 || B < 0 || S < 1 || max_len < 1) return 0;
+    return carve_decode(m, B, S, max_len, nullptr, nullptr);
+}
+
+int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, int S, int max_len, int sos, int eos,
+                            int flags, void* workspace, size_t workspace_bytes, int64_t* out_ids, int32_t* out_len,
+                            int32_t* out_dirty, void* stream) {
+    CAPDEC_TRY(check_model(m));
+    CAPDEC_REQUIRE(enc && out_ids && out_len && B >= 0 && S >= 1 && S <= 2048 && max_len >= 1);
+    CAPDEC_REQUIRE(max_len <= m->max_pos);           // the reference's pe buffer has max_pos rows
+    CAPDEC_REQUIRE(sos >= 0 && sos < m->V);
+    if (B == 0) return 0;
+    if (!workspace || !capdec_aligned16(workspace) || !capdec_aligned16(enc)) return CAPDEC_EALIGN;
+    DecodeWs w;
+    if (carve_decode(m, B, S, max_len, workspace, &w) > workspace_bytes) return CAPDEC_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->E, H = m->H, dk = E / H, L = m->L, V = m->V;
+    const int64_t ldtok = max_len + 1;
+    const size_t BE = (size_t)B * E;
+    const bool s1 = (S == 1) && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT);
+
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, out_ids, out_len,
+                       out_dirty, B, max_len, sos);
+    CAPDEC_LAUNCH_CHECK();
+    CAPDEC_TRY(capdec_embed_pe(w.tok, 1, ldtok, m->emb, m->pe, 0, B, 1, E, V, w.x, stream));
+
+    if (s1) {
+        // softmax over one key is exactly 1, so the block's output is W_o(W_v enc + b_v) + b_o for every
+        // query: one vector per sample and layer, computed once
+        for (int l = 0; l < L; ++l) {
+            const capdec_attn_w& a = m->layers[l].cross_attn;
+            CAPDEC_TRY(linear(enc, E, B, a.wv, a.bv, E, E, w.ao, E, nullptr, 0, 0, s));
+            CAPDEC_TRY(linear(w.ao, E, B, a.wo, a.bo, E, E, w.cc + l * BE, E, nullptr, 0, 0, s));
+        }
+    } else {
+        CAPDEC_TRY(project_memory(m, enc, B, S, w.ck, w.cv, s));
+    }
+
+    const int nt = capdec_vocab_tiles(V);
+    for (int t = 0; t < max_len; ++t) {
+        for (int l = 0; l < L; ++l) {
+            const capdec_tf_layer& ly = m->layers[l];
+            float* kc = w.kc + (size_t)l * BE * max_len;
+            float* vc = w.vc + (size_t)l * BE * max_len;
+            // q, and this position's k/v straight into the cache rows
+            capdec_gemm_group g[3];
+            g[0] = linear_group(w.x, E, B, ly.self_attn.wq, ly.self_attn.bq, E, w.q, E);
+            g[1] = linear_group(w.x, E, B, ly.self_attn.wk, ly.self_attn.bk, E, kc + (size_t)t * E, (int64_t)max_len * E);
+            g[2] = linear_group(w.x, E, B, ly.self_attn.wv, ly.self_attn.bv, E, vc + (size_t)t * E, (int64_t)max_len * E);
+            g[0].ldq = g[1].ldq = g[2].ldq = E;
+            CAPDEC_TRY(capdec_launch_gemm(g, 3, E, 0, s));
+            CAPDEC_TRY(capdec_attention(w.q, E, kc, E, (int64_t)max_len * E, vc, E, (int64_t)max_len * E, w.ao, E, B, H,
+                                        1, t + 1, dk, 0, 0, w.tok + t, ldtok, nullptr, stream));
+            CAPDEC_TRY(linear(w.ao, E, B, ly.self_attn.wo, ly.self_attn.bo, E, E, w.y, E, w.x, E, 0, s));
+            CAPDEC_TRY(capdec_add_layernorm(w.y, nullptr, 1, ly.n1_g, ly.n1_b, 1e-5f, B, E, w.x1, nullptr, nullptr,
+                                            stream));
+            if (s1) {
+                CAPDEC_TRY(capdec_add_layernorm(w.x1, w.cc + l * BE, 1, ly.n2_g, ly.n2_b, 1e-5f, B, E, w.x2, nullptr,
+                                                nullptr, stream));
+            } else {
+                CAPDEC_TRY(linear(w.x1, E, B, ly.cross_attn.wq, ly.cross_attn.bq, E, E, w.q, E, nullptr, 0, 0, s));
+                CAPDEC_TRY(capdec_attention(w.q, E, w.ck + (size_t)l * BE * S, E, (int64_t)S * E,
+                                            w.cv + (size_t)l * BE * S, E, (int64_t)S * E, w.ao, E, B, H, 1, S, dk, 0, 0,
+                                            nullptr, 0, nullptr, stream));
+                CAPDEC_TRY(linear(w.ao, E, B, ly.cross_attn.wo, ly.cross_attn.bo, E, E, w.y, E, w.x1, E, 0, s));
+                CAPDEC_TRY(capdec_add_layernorm(w.y, nullptr, 1, ly.n2_g, ly.n2_b, 1e-5f, B, E, w.x2, nullptr, nullptr,
+                                                stream));
+            }
+            CAPDEC_TRY(linear(w.x2, E, B, ly.ff_w1, ly.ff_b1, E, E, w.hb, E, nullptr, 0, CAPDEC_GEMM_RELU, s));
+            CAPDEC_TRY(linear(w.hb, E, B, ly.ff_w2, ly.ff_b2, E, E, w.y, E, w.x2, E, 0, s));
+            CAPDEC_TRY(capdec_add_layernorm(w.y, nullptr, 1, ly.n3_g, ly.n3_b, 1e-5f, B, E, w.x, nullptr, nullptr,
+                                            stream));
+        }
+        CAPDEC_TRY(capdec_vocab_argmax_partial(w.x, E, m->fc2_w, m->fc2_b, B, V, E, w.pval, w.pidx, stream));
+        const bool last = (t + 1 == max_len);
+        hipLaunchKernelGGL(greedy_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
+                           eos, w.tok, ldtok, w.done, out_ids, out_len, out_dirty, m->emb, m->pe, E, V,
+                           last ? nullptr : w.x);
+        CAPDEC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// =================================================================================================
+// Full-prefix paths: exact greedy decode and teacher-forced logits
+// =================================================================================================
+struct FullWs {
+    FullBufs f;
+    float *ck, *cv;
+    float* pval; int32_t* pidx;
+    int32_t *tok, *done;
+};
+
+static size_t carve_full(const capdec_tf_model* m, int B, int S, int T, bool decode, void* base, FullWs* w) {
+    Carver c(base);
+    const size_t n = (size_t)B * T * m->E;
+    FullWs d;
+    d.f.X = c.take<float>(n); d.f.Y = c.take<float>(n); d.f.X1 = c.take<float>(n); d.f.X2 = c.take<float>(n);
+    d.f.Qb = c.take<float>(n); d.f.Kb = c.take<float>(n); d.f.Vb = c.take<float>(n); d.f.AO = c.take<float>(n);
+    d.f.Hb = c.take<float>(n);
+    d.ck = c.take<float>((size_t)m->L * B * S * m->E);
+    d.cv = c.take<float>((size_t)m->L * B * S * m->E);
+    const size_t nt = (size_t)capdec_vocab_tiles(m->V);
+    d.pval = c.take<float>(decode ? (size_t)B * nt : 1);
+    d.pidx = c.take<int32_t>(decode ? (size_t)B * nt : 1);
+    d.tok = c.take<int32_t>((size_t)B * (T + 1));
+    d.done = c.take<int32_t>((size_t)B);
+    if (w) *w = d;
+    return c.off;
+}
+
+size_t capdec_tf_exact_workspace_bytes(const capdec_tf_model* m, int B, int S, int max_len) {
+    if (check_model(m) != 0 || B < 0 || S < 1 || max_len < 1) return 0;
+    return carve_full(m, B, S, max_len, true, nullptr, nullptr);
+}
+
+int capdec_tf_greedy_decode_exact(const capdec_tf_model* m, const float* enc, int B, int S, int max_len, int sos,
+                                  int eos, void* workspace, size_t workspace_bytes, int64_t* out_ids, int32_t* out_len,
+                                  void* stream) {
+    CAPDEC_TRY(check_model(m));
+    CAPDEC_REQUIRE(enc && out_ids && out_len && B >= 0 && S >= 1 && S <= 2048 && max_len >= 1);
+    CAPDEC_REQUIRE(max_len <= m->max_pos && sos >= 0 && sos < m->V);
+    if (B == 0) return 0;
+    if (!workspace || !capdec_aligned16(workspace) || !capdec_aligned16(enc)) return CAPDEC_EALIGN;
+    FullWs w;
+    if (carve_full(m, B, S, max_len, true, workspace, &w) > workspace_bytes) return CAPDEC_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->E, V = m->V;
+    const int64_t ldtok = max_len + 1;
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, out_ids, out_len,
+                       (int32_t*)nullptr, B, max_len, sos);
+    CAPDEC_LAUNCH_CHECK();
+    CAPDEC_TRY(project_memory(m, enc, B, S, w.ck, w.cv, s));
+    const int nt = capdec_vocab_tiles(V);
+    for (int t = 0; t < max_len; ++t) {
+        const int T = t + 1;   // the whole prefix, every step (transformer.py:152)
+        CAPDEC_TRY(capdec_embed_pe(w.tok, 1, ldtok, m->emb, m->pe, 0, B, T, E, V, w.f.X, stream));
+        CAPDEC_TRY(decoder_stack_full(m, w.f, w.ck, w.cv, B, S, T, w.tok, ldtok, s));
+        // take_last: row (b, T-1) of X
+        CAPDEC_TRY(capdec_vocab_argmax_partial(w.f.X + (size_t)(T - 1) * E, (int64_t)T * E, m->fc2_w, m->fc2_b, B, V, E,
+                                               w.pval, w.pidx, stream));
+        hipLaunchKernelGGL(greedy_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
+                           eos, w.tok, ldtok, w.done, out_ids, out_len, (int32_t*)nullptr, m->emb, m->pe, E, V,
+                           (float*)nullptr);
+        CAPDEC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+size_t capdec_tf_forward_workspace_bytes(const capdec_tf_model* m, int B, int S, int T) {
+    if (check_model(m) != 0 || B < 0 || S < 1 || T < 1) return 0;
+    return carve_full(m, B, S, T, false, nullptr, nullptr);
+}
+
+__global__ void ids_to_i32_kernel(const int64_t* __restrict__ in, int32_t* __restrict__ out, int B, int T, int64_t ldo) {
+    const int n = B * T;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const int b = idx / T, i = idx - b * T;
+        out[(int64_t)b * ldo + i] = (int32_t)in[idx];
+    }
+}
+
+int capdec_tf_forward_logits(const capdec_tf_model* m, const float* enc, const int64_t* ids, int B, int S, int T,
+                             int take_last, void* workspace, size_t workspace_bytes, float* logits, void* stream) {
+    CAPDEC_TRY(check_model(m));
+    CAPDEC_REQUIRE(enc && ids && logits && B >= 0 && S >= 1 && S <= 2048 && T >= 1 && T <= m->max_pos && T <= 2048);
+    if (B == 0) return 0;
+    if (!workspace || !capdec_aligned16(workspace) || !capdec_aligned16(enc) || !capdec_aligned16(logits))
+        return CAPDEC_EALIGN;
+    FullWs w;
+    if (carve_full(m, B, S, T, false, workspace, &w) > workspace_bytes) return CAPDEC_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->E, V = m->V;
+    const int64_t ldtok = T + 1;
+    hipLaunchKernelGGL(ids_to_i32_kernel, dim3(256), dim3(256), 0, s, ids, w.tok, B, T, ldtok);
+    CAPDEC_LAUNCH_CHECK();
+    CAPDEC_TRY(capdec_embed_pe(ids, 0, T, m->emb, m->pe, 0, B, T, E, V, w.f.X, stream));
+    CAPDEC_TRY(project_memory(m, enc, B, S, w.ck, w.cv, s));
+    CAPDEC_TRY(decoder_stack_full(m, w.f, w.ck, w.cv, B, S, T, w.tok, ldtok, s));
+    if (take_last)
+        return linear(w.f.X + (size_t)(T - 1) * E, (int64_t)T * E, B, m->fc2_w, m->fc2_b, V, E, logits, V, nullptr, 0, 0, s);
+    return linear(w.f.X, E, B * T, m->fc2_w, m->fc2_b, V, E, logits, V, nullptr, 0, 0, s);
+}
+
+// =================================================================================================
+// CNN-RNN greedy decode
+// =================================================================================================
+struct RnnWs {
+    float *x, *h[2], *c[2];
+    float* pval; int32_t* pidx;
+    int32_t *tok, *done;
+};
+
+static size_t carve_rnn(const capdec_rnn_model* m, int B, int max_len, void* base, RnnWs* w) {
+    Carver c(base);
+    RnnWs d;
+    d.x = c.take<float>((size_t)B * m->E);
+    for (int n = 0; n < 2; ++n) {
+        d.h[n] = c.take<float>((size_t)B * m->Hd);
+        d.c[n] = c.take<float>((size_t)B * m->Hd);
+    }
+    const size_t nt = (size_t)capdec_vocab_tiles(m->V);
+    d.pval = c.take<float>((size_t)B * nt);
+    d.pidx = c.take<int32_t>((size_t)B * nt);
+    d.tok = c.take<int32_t>((size_t)B * (max_len + 1));
+    d.done = c.take<int32_t>((size_t)B);
+    if (w) *w = d;
+    return c.off;
+}
+
+static int check_rnn(const capdec_rnn_model* m) {
+    CAPDEC_REQUIRE(m && m->E >= 4 && m->E % 4 == 0 && m->Hd >= 4 && m->Hd % 4 == 0 && m->V >= 1);
+    CAPDEC_REQUIRE(m->emb && m->w_ih && m->w_hh && m->b_ih && m->b_hh && m->fc2_w && m->fc2_b);
+    return 0;
+}
+
+size_t capdec_rnn_decode_workspace_bytes(const capdec_rnn_model* m, int B, int max_len) {
+    if (check_rnn(m) != 0 || B < 0 || max_len < 1) return 0;
+    return carve_rnn(m, B, max_len, nullptr, nullptr);
+}
+
+int capdec_rnn_greedy_decode(const capdec_rnn_model* m, const float* x0, int B, int max_len, int sos, int eos,
+                             void* workspace, size_t workspace_bytes, int64_t* out_ids, int32_t* out_len,
+                             void* stream) {
+    CAPDEC_TRY(check_rnn(m));
+    CAPDEC_REQUIRE(x0 && out_ids && out_len && B >= 0 && max_len >= 1 && sos >= 0 && sos < m->V);
+    if (B == 0) return 0;
+    if (!workspace || !capdec_aligned16(workspace)) return CAPDEC_EALIGN;
+    RnnWs w;
+    if (carve_rnn(m, B, max_len, workspace, &w) > workspace_bytes) return CAPDEC_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->E, Hd = m->Hd, V = m->V;
+    const int64_t ldtok = max_len + 1;
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, out_ids, out_len,
+                       (int32_t*)nullptr, B, max_len, sos);
+    CAPDEC_LAUNCH_CHECK();
+    // the image is time-step 0 of the LSTM, from the zero state (cnnrnn_model.py:75)
+    CAPDEC_TRY(capdec_lstm_step(x0, E, nullptr, 0, nullptr, m->w_ih, m->w_hh, m->b_ih, m->b_hh, B, E, Hd, w.h[0], Hd,
+                                w.c[0], nullptr, stream));
+    CAPDEC_TRY(capdec_embed_pe(w.tok, 1, ldtok, m->emb, nullptr, 0, B, 1, E, V, w.x, stream));
+    const int nt = capdec_vocab_tiles(V);
+    int cur = 0;
+    for (int t = 0; t < max_len; ++t) {
+        CAPDEC_TRY(capdec_lstm_step(w.x, E, w.h[cur], Hd, w.c[cur], m->w_ih, m->w_hh, m->b_ih, m->b_hh, B, E, Hd,
+                                    w.h[cur ^ 1], Hd, w.c[cur ^ 1], nullptr, stream));
+        cur ^= 1;
+        CAPDEC_TRY(capdec_vocab_argmax_partial(w.h[cur], Hd, m->fc2_w, m->fc2_b, B, V, Hd, w.pval, w.pidx, stream));
+        const bool last = (t + 1 == max_len);
+        hipLaunchKernelGGL(greedy_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
+                           eos, w.tok, ldtok, w.done, out_ids, out_len, (int32_t*)nullptr, m->emb,
+                           (const float*)nullptr, E, V, last ? nullptr : w.x);
+        CAPDEC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // extern "C"

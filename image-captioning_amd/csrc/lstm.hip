@@ -1,0 +1,165 @@
+// Fused LSTM step for gfx950: the gate contraction [B, E+Hd] x [E+Hd, 4Hd] on fp32 MFMA with the
+// gate non-linearities and the cell update in the epilogue (nn.LSTM gate order i,f,g,o).
+//
+// A wavefront owns 32 samples x 32 hidden units and keeps FOUR 32x32 accumulators, one per gate, with
+// identical (sample, unit) -> (register, lane) maps, so c' and h' are computed in registers and the
+// [B,4Hd] gate tensor is never written (unless the caller asks for it for a backward pass).
+// The k loop runs over two operand pairs back to back: (x, W_ih) then (h, W_hh).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 36;
+constexpr int TB = 64;                 // samples per workgroup
+constexpr int TU = 64;                 // hidden units per workgroup
+constexpr int LSTM_LDS_FLOATS = 2 * (TB + 4 * TU) * LDK;
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, int64_t ld, int row, int nrows, int k, int K) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < nrows) {
+        const float* p = base + (int64_t)row * ld + k;
+        if (VEC) {
+            if (k < K) v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+            if (k + 0 < K) v[0] = p[0];
+            if (k + 1 < K) v[1] = p[1];
+            if (k + 2 < K) v[2] = p[2];
+            if (k + 3 < K) v[3] = p[3];
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct LstmArgs {
+    const float* x; int64_t ldx;
+    const float* h0; int64_t ldh0; const float* c0;
+    const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh;
+    int B, E, Hd;
+    float* h1; int64_t ldh1; float* c1; float* gates;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ps = lds;                       // [2][TB][LDK]
+    float* Qs = lds + 2 * TB * LDK;        // [2][4*TU][LDK], row = gate*TU + local unit
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;
+    const int i0 = blockIdx.y * TB, u0 = blockIdx.x * TU;
+    const int nkx = (a.E + BK - 1) / BK;
+    const int nkh = a.h0 ? (a.Hd + BK - 1) / BK : 0;
+    const int nk = nkx + nkh;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+
+    f32x4 pr[TB / 32], qr[4 * TU / 32];
+    auto gload = [&](int kt) {
+        const bool second = kt >= nkx;
+        const float* P = second ? a.h0 : a.x;
+        const float* W = second ? a.w_hh : a.w_ih;
+        const int64_t ldp = second ? a.ldh0 : a.ldx;
+        const int K = second ? a.Hd : a.E;
+        const int k = (second ? kt - nkx : kt) * BK + lk;
+#pragma unroll
+        for (int p = 0; p < TB / 32; ++p) pr[p] = ld4<VEC>(P, ldp, i0 + lrow + 32 * p, a.B, k, K);
+#pragma unroll
+        for (int p = 0; p < 4 * TU / 32; ++p) {
+            const int qrow = lrow + 32 * p;            // gate*TU + local unit
+            const int g = qrow / TU, ul = qrow - g * TU;
+            const int u = u0 + ul;
+            qr[p] = (u < a.Hd) ? ld4<VEC>(W, (int64_t)K, g * a.Hd + u, 4 * a.Hd, k, K) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < TB / 32; ++p)
+            *reinterpret_cast<f32x4*>(&Ps[(buf * TB + lrow + 32 * p) * LDK + lk]) = pr[p];
+#pragma unroll
+        for (int p = 0; p < 4 * TU / 32; ++p)
+            *reinterpret_cast<f32x4*>(&Qs[(buf * 4 * TU + lrow + 32 * p) * LDK + lk]) = qr[p];
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        const float* pa = &Ps[(cur * TB + wi * 32 + r) * LDK + 4 * h];
+        const float* qa = &Qs[(cur * 4 * TU + wj * 32 + r) * LDK + 4 * h];
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(pa + kc * 8);
+            f32x4 bv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(qa + g * TU * LDK + kc * 8);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[g][m], acc[g], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const int u = u0 + wj * 32 + r;
+    if (u >= a.Hd) return;
+    float bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = a.b_ih[g * a.Hd + u] + a.b_hh[g * a.Hd + u];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + wi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (i >= a.B) continue;
+        const float gi = acc[0][e] + bias[0], gf = acc[1][e] + bias[1];
+        const float gg = acc[2][e] + bias[2], go = acc[3][e] + bias[3];
+        const float cp = a.c0 ? a.c0[(int64_t)i * a.Hd + u] : 0.f;
+        const float cn = sigmoidf_(gf) * cp + sigmoidf_(gi) * tanhf(gg);
+        const float hn = sigmoidf_(go) * tanhf(cn);
+        a.c1[(int64_t)i * a.Hd + u] = cn;
+        a.h1[(int64_t)i * a.ldh1 + u] = hn;
+        if (a.gates) {
+            float* gp = a.gates + (int64_t)i * 4 * a.Hd + u;
+            gp[0] = gi; gp[a.Hd] = gf; gp[2 * a.Hd] = gg; gp[3 * a.Hd] = go;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, const float* w_ih,
+                                const float* w_hh, const float* b_ih, const float* b_hh, int B, int E, int Hd,
+                                float* h1, int64_t ldh1, float* c1, float* gates_out, void* stream) {
+    CAPDEC_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && h1 && c1 && B >= 0 && E >= 1 && Hd >= 1);
+    CAPDEC_REQUIRE(ldx >= E && ldh1 >= Hd && (!h0 || ldh0 >= Hd));
+    CAPDEC_REQUIRE(h1 != h0 && c1 != c0);   // other workgroups still read the old state
+    if (B == 0) return 0;
+    LstmArgs a{x, ldx, h0, ldh0, c0, w_ih, w_hh, b_ih, b_hh, B, E, Hd, h1, ldh1, c1, gates_out};
+    const bool vec = E % 4 == 0 && Hd % 4 == 0 && ldx % 4 == 0 && capdec_aligned16(x) && capdec_aligned16(w_ih) &&
+                     capdec_aligned16(w_hh) && (!h0 || (capdec_aligned16(h0) && ldh0 % 4 == 0));
+    constexpr size_t smem = LSTM_LDS_FLOATS * sizeof(float);
+    static const bool ready =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+    if (!ready) return CAPDEC_EINVAL;
+    dim3 grid((Hd + TU - 1) / TU, (B + TB - 1) / TB);
+    if (vec) hipLaunchKernelGGL(lstm_step_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(lstm_step_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}

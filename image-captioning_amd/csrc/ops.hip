@@ -1,0 +1,325 @@
+// Row-wise kernels of the caption decoder for gfx950: embedding gather + positional encoding,
+// residual-add LayerNorm, fused (masked / cross) attention.  All are HBM-bound; each uses one 64-lane
+// wavefront per row with 16-byte accesses and shuffle reductions (no LDS except the score row).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// ---- x[b*T+i,:] = emb[ids[b,i],:] + pe[pos0+i,:] ------------------------------------------------
+template <typename IdT>
+__global__ __launch_bounds__(256) void embed_pe_kernel(const IdT* __restrict__ ids, int64_t ldid,
+                                                       const float* __restrict__ emb, const float* __restrict__ pe,
+                                                       int pos0, int rows, int T, int E, int V,
+                                                       float* __restrict__ x) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int b = row / T, i = row - b * T;
+    long id = (long)ids[(int64_t)b * ldid + i];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const f32x4* src = reinterpret_cast<const f32x4*>(emb + id * (int64_t)E);
+    const f32x4* pp = pe ? reinterpret_cast<const f32x4*>(pe + (int64_t)(pos0 + i) * E) : nullptr;
+    f32x4* dst = reinterpret_cast<f32x4*>(x + (int64_t)row * E);
+    for (int c = lane; c < E / 4; c += 64) {
+        f32x4 v = src[c];
+        if (pp) v += pp[c];
+        dst[c] = v;
+    }
+}
+
+// ---- y = LayerNorm(x + add) * gamma + beta ------------------------------------------------------
+constexpr int LN_MAXV = 8;   // float4 per lane: E <= 2048
+
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                            int add_div, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, int M, int E,
+                                                            float* __restrict__ y, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nv = E / 4;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * E);
+    const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (int64_t)(row / add_div) * E) : nullptr;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+        const int c = lane + 64 * u;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            v[u] = xr[c];
+            if (ar) v[u] += ar[c];
+            s += v[u][0] + v[u][1] + v[u][2] + v[u][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nv) {
+            v[u] -= mean;
+            q += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+        }
+    }
+    const float var = wave_sum(q) / (float)E;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    f32x4* yr = reinterpret_cast<f32x4*>(y + (int64_t)row * E);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nv) yr[c] = v[u] * rstd * g4[c] + b4[c];
+    }
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+// ---- fused attention, one wavefront per (b, h, query row) ---------------------------------------
+struct AttnArgs {
+    const float* q; int64_t ldq;
+    const float* k; int64_t ldk, sk;
+    const float* v; int64_t ldv, sv;
+    float* out; int64_t ldo;
+    int B, H, Tq, Tk, dk;
+    int causal, causal_off;
+    const int32_t* ids; int64_t ldid;
+    float* lse;
+};
+
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long total = (long)a.B * a.H * a.Tq;
+    long idx = (long)blockIdx.x * 4 + wave;
+    const bool live = idx < total;
+    if (!live) idx = total - 1;            // keep the wave in the barriers; it stores nothing
+    const int i = (int)(idx % a.Tq);
+    const int h = (int)((idx / a.Tq) % a.H);
+    const int b = (int)(idx / ((long)a.Tq * a.H));
+    float* sc = lds + wave * a.Tk;         // this wave's score row
+
+    const bool pad_row = a.ids && a.ids[(int64_t)b * a.ldid + i] == 0;
+    int nkeys = a.Tk;
+    if (a.causal && !pad_row) {
+        nkeys = i + a.causal_off + 1;
+        nkeys = nkeys < 1 ? 1 : (nkeys > a.Tk ? a.Tk : nkeys);
+    }
+    const int dk = a.dk;
+    const float* kb = a.k + (int64_t)b * a.sk + (int64_t)h * dk;
+    const float* vb = a.v + (int64_t)b * a.sv + (int64_t)h * dk;
+
+    float mx = 0.f, sum = 1.f;
+    if (!pad_row) {
+        // scores: 4 lanes per key, each lane owns dims {4*part + 16*m}
+        const int part = lane & 3, kl = lane >> 2;
+        const float* qp = a.q + ((int64_t)b * a.Tq + i) * a.ldq + (int64_t)h * dk + 4 * part;
+        const int nm = dk / 16;
+        f32x4 qreg[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            qreg[m] = (m < nm) ? *reinterpret_cast<const f32x4*>(qp + 16 * m) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float scale = sqrtf((float)dk);
+        for (int j0 = 0; j0 < nkeys; j0 += 16) {
+            const int j = j0 + kl;
+            float d = 0.f;
+            if (j < nkeys) {
+                const float* kp = kb + (int64_t)j * a.ldk + 4 * part;
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    if (m < nm) {
+                        const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 16 * m);
+                        d += qreg[m][0] * kk[0] + qreg[m][1] * kk[1] + qreg[m][2] * kk[2] + qreg[m][3] * kk[3];
+                    }
+            }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            if (part == 0 && j < nkeys) sc[j] = d / scale;
+        }
+    }
+    __syncthreads();
+    if (!pad_row) {
+        float m = -INFINITY;
+        for (int j = lane; j < nkeys; j += 64) m = fmaxf(m, sc[j]);
+        mx = wave_max(m);
+        float s = 0.f;
+        for (int j = lane; j < nkeys; j += 64) {
+            const float e = expf(sc[j] - mx);
+            sc[j] = e;
+            s += e;
+        }
+        sum = wave_sum(s);
+    } else {
+        // every score is the same fill value: exp(0) = 1 for each of the Tk keys
+        for (int j = lane; j < nkeys; j += 64) sc[j] = 1.f;
+        mx = -1e9f;
+        sum = (float)nkeys;
+    }
+    __syncthreads();
+    // P.V: dk/4 lanes per key (one float4 of the head each), 64/(dk/4) keys in flight
+    const int lpv = dk / 4;
+    const int grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = grp; j < nkeys; j += ngrp) {
+        const float p = sc[j] / sum;
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * a.ldv + 4 * dl);
+        acc += vv * p;
+    }
+    for (int o = lpv; o < 64; o <<= 1) {
+        acc[0] += __shfl_xor(acc[0], o, 64);
+        acc[1] += __shfl_xor(acc[1], o, 64);
+        acc[2] += __shfl_xor(acc[2], o, 64);
+        acc[3] += __shfl_xor(acc[3], o, 64);
+    }
+    if (live && grp == 0)
+        *reinterpret_cast<f32x4*>(a.out + ((int64_t)b * a.Tq + i) * a.ldo + (int64_t)h * dk + 4 * dl) = acc;
+    if (live && lane == 0 && a.lse) a.lse[idx] = mx + logf(sum);
+}
+
+// ---- BatchNorm1d on [B, C] ----------------------------------------------------------------------
+// eval: fold the running statistics into a per-column scale/shift for a GEMM epilogue
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// train: batch statistics per column (two passes: mean, then centred variance), normalise, and update
+// the running buffers (biased variance normalises, unbiased variance feeds the running average).
+// 64 columns per workgroup; lane = column, the 4 wavefronts stride the rows.
+__global__ __launch_bounds__(256) void bn_train_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, float momentum,
+                                                       float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, int B, int C,
+                                                       float* __restrict__ y, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_rstd) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < C;
+    float s = 0.f;
+    if (ok)
+        for (int r = wave; r < B; r += 4) s += x[(int64_t)r * C + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)B;
+    __syncthreads();
+    float q = 0.f;
+    if (ok)
+        for (int r = wave; r < B; r += 4) {
+            const float d = x[(int64_t)r * C + c] - mean;
+            q += d * d;
+        }
+    red[wave][lane] = q;
+    __syncthreads();
+    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)B;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (!ok) return;
+    const float g = gamma[c], bt = beta[c];
+    for (int r = wave; r < B; r += 4) y[(int64_t)r * C + c] = (x[(int64_t)r * C + c] - mean) * rstd * g + bt;
+    if (wave == 0) {
+        if (save_mean) save_mean[c] = mean;
+        if (save_rstd) save_rstd[c] = rstd;
+        if (running_mean) {
+            const float unbiased = var * ((float)B / (float)(B - 1));
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int capdec_abi_version(void) { return CAPDEC_ABI_VERSION; }
+
+const char* capdec_strerror(int code) {
+    switch (code) {
+        case CAPDEC_OK: return "ok";
+        case CAPDEC_EINVAL: return "capdec: invalid argument (shape, null pointer or unsupported size)";
+        case CAPDEC_ENOMEM: return "capdec: workspace too small";
+        case CAPDEC_EALIGN: return "capdec: pointer or stride not 16-byte aligned";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "capdec: unknown error";
+    }
+}
+
+int capdec_embed_pe(const void* ids, int ids32, int64_t ldid, const float* emb, const float* pe, int pos0, int B, int T,
+                    int E, int V, float* x, void* stream) {
+    CAPDEC_REQUIRE(ids && emb && x && B >= 0 && T >= 1 && E >= 4 && E % 4 == 0 && V >= 1 && pos0 >= 0 && ldid >= T);
+    if (!capdec_aligned16(emb) || !capdec_aligned16(x) || (pe && !capdec_aligned16(pe))) return CAPDEC_EALIGN;
+    const int rows = B * T;
+    if (rows == 0) return 0;
+    dim3 grid((rows + 3) / 4), block(256);
+    if (ids32)
+        hipLaunchKernelGGL(embed_pe_kernel<int32_t>, grid, block, 0, (hipStream_t)stream, (const int32_t*)ids, ldid,
+                           emb, pe, pos0, rows, T, E, V, x);
+    else
+        hipLaunchKernelGGL(embed_pe_kernel<int64_t>, grid, block, 0, (hipStream_t)stream, (const int64_t*)ids, ldid,
+                           emb, pe, pos0, rows, T, E, V, x);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_add_layernorm(const float* x, const float* add, int add_div, const float* gamma, const float* beta,
+                         float eps, int M, int E, float* y, float* mean, float* rstd, void* stream) {
+    CAPDEC_REQUIRE(x && gamma && beta && y && M >= 0 && E >= 4 && E % 4 == 0 && E <= 256 * LN_MAXV);
+    CAPDEC_REQUIRE(!add || add_div >= 1);
+    if (!capdec_aligned16(x) || !capdec_aligned16(y) || !capdec_aligned16(gamma) || !capdec_aligned16(beta) ||
+        (add && !capdec_aligned16(add)))
+        return CAPDEC_EALIGN;
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add,
+                       add ? add_div : 1, gamma, beta, eps, M, E, y, mean, rstd);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v, int64_t ldv,
+                     int64_t sv, float* out, int64_t ldo, int B, int H, int Tq, int Tk, int dk, int causal,
+                     int causal_off, const int32_t* ids, int64_t ldid, float* lse, void* stream) {
+    CAPDEC_REQUIRE(q && k && v && out && B >= 0 && H >= 1 && Tq >= 1 && Tk >= 1 && Tk <= 2048);
+    CAPDEC_REQUIRE(dk == 16 || dk == 32 || dk == 64 || dk == 128 || dk == 256);
+    CAPDEC_REQUIRE(!ids || ldid >= Tq);
+    if (!capdec_aligned16(q) || !capdec_aligned16(k) || !capdec_aligned16(v) || !capdec_aligned16(out) || ldq % 4 ||
+        ldk % 4 || sk % 4 || ldv % 4 || sv % 4 || ldo % 4)
+        return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    AttnArgs a{q, ldq, k, ldk, sk, v, ldv, sv, out, ldo, B, H, Tq, Tk, dk, causal, causal_off, ids, ldid, lse};
+    const long total = (long)B * H * Tq;
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 4 * Tk * sizeof(float),
+                       (hipStream_t)stream, a);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                   float eps, int C, float* scale, float* shift, void* stream) {
+    CAPDEC_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C >= 1);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_bn_train_forward(const float* x, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, int B, int C, float* y, float* save_mean,
+                            float* save_rstd, void* stream) {
+    CAPDEC_REQUIRE(x && gamma && beta && y && B >= 2 && C >= 1);
+    CAPDEC_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    hipLaunchKernelGGL(bn_train_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
+                       momentum, running_mean, running_var, B, C, y, save_mean, save_rstd);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

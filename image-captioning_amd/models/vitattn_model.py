@@ -1,0 +1,46 @@
+"""ViT-Attn: ViT-B/16 output [B,1000] -> one memory row -> Transformer decoder.
+
+Drop-in for the reference's ``models/vitattn_model.py`` (vitattn_model.py:21-66): same constructor, ``forward`` /
+``caption_images`` signatures and ``state_dict`` keys (minus the frozen backbone, whose features are this
+model's input).  All arithmetic runs on the gfx950 kernels of libcapdec.so.
+"""
+import torch
+import torch.nn as nn
+
+from models.modules import heads
+from models.modules.transformer import DecoderTransformer
+
+
+class VITAttentionModel(DecoderTransformer):
+    def __init__(self, embed_size, vocab_size, num_heads, num_layers, dropout=0.1, max_seq_length=50):
+        super().__init__(embed_size, vocab_size, num_heads, num_layers, dropout, max_seq_length)
+        self.vit_out_size = 1000
+        self.fc_vit = nn.Linear(1000, embed_size)
+        self.dropout = nn.Dropout(dropout)
+        self.batchnorm = nn.BatchNorm1d(1 * embed_size)
+
+    def precompute_image(self, images):
+        raise RuntimeError(heads.BACKBONE_MSG)
+
+    def encode_features(self, images, mode="precomputed"):
+        """Feature head: fc_vit -> dropout -> BatchNorm1d(E) -> [B,1,E]"""
+        return heads.single_head(self, self.fc_vit, images, mode)
+
+    def forward(self, images, captions, mode):
+        return self.decoder_forward(self.encode_features(images, mode), captions)
+
+    def caption_images(self, images, vocabulary, mode="precomputed", max_length=40):
+        self.eval()
+        with torch.no_grad():
+            enc_output = self.encode_features(images, mode)
+        return self.greedy_inference(enc_output, vocabulary, max_length)
+
+    def caption_ids(self, images, sos=1, eos=2, mode="precomputed", max_length=40):
+        """Greedy decode returning token ids: (ids int64 [B,max_length] padded with -1, lengths [B])."""
+        self.eval()
+        with torch.no_grad():
+            enc_output = self.encode_features(images, mode)
+            return self.greedy_ids(enc_output, sos, eos, max_length)
+
+    def caption_images_beam_search(self, images, vocabulary, beam_width=3, mode="precomputed", max_length=50):
+        raise NotImplementedError("beam search is not part of the MI355X hot path yet (greedy only)")
