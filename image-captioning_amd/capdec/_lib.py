@@ -42,6 +42,10 @@ class RnnModel(Structure):
                 ("w_hh", c_void_p), ("b_ih", c_void_p), ("b_hh", c_void_p), ("fc2_w", c_void_p), ("fc2_b", c_void_p)]
 
 
+class Probe(Structure):
+    _fields_ = [("begin", POINTER(c_void_p)), ("end", POINTER(c_void_p)), ("n", c_int32)]
+
+
 _P = c_void_p
 _SIGNATURES = {
     "capdec_abi_version": (c_int, []),
@@ -61,7 +65,11 @@ _SIGNATURES = {
     "capdec_bn_train_forward": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "capdec_tf_decode_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int]),
     "capdec_tf_greedy_decode": (c_int, [POINTER(TfModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t,
-                                        _P, _P, _P, _P]),
+                                        _P, _P, _P, POINTER(Probe), _P]),
+    "capdec_event_create": (c_int, [POINTER(c_void_p)]),
+    "capdec_event_destroy": (c_int, [_P]),
+    "capdec_event_record": (c_int, [_P, _P]),
+    "capdec_event_elapsed_ms": (c_int, [_P, _P, POINTER(c_float)]),
     "capdec_tf_exact_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int]),
     "capdec_tf_greedy_decode_exact": (c_int, [POINTER(TfModel), _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t,
                                               _P, _P, _P]),

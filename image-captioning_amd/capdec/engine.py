@@ -56,9 +56,45 @@ def _workspace(nbytes, device):
     return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
 
 
-def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=False, resolve_dirty=True):
+class VocabProbe:
+    """HIP events around the vocabulary-projection kernel of each decode step (benchmark plumbing)."""
+
+    def __init__(self, n):
+        lib = _lib.load()
+        self.n = n
+        self.begin = (ctypes.c_void_p * n)()
+        self.end = (ctypes.c_void_p * n)()
+        for arr in (self.begin, self.end):
+            for i in range(n):
+                ev = ctypes.c_void_p()
+                _lib.check(lib.capdec_event_create(ctypes.byref(ev)), "capdec_event_create")
+                arr[i] = ev
+        self.c = _lib.Probe(ctypes.cast(self.begin, ctypes.POINTER(ctypes.c_void_p)),
+                            ctypes.cast(self.end, ctypes.POINTER(ctypes.c_void_p)), n)
+
+    def elapsed_ms(self):
+        """Per-step kernel durations; call after the stream has been synchronised."""
+        lib = _lib.load()
+        out = []
+        for i in range(self.n):
+            ms = ctypes.c_float()
+            _lib.check(lib.capdec_event_elapsed_ms(self.begin[i], self.end[i], ctypes.byref(ms)), "capdec_event_elapsed_ms")
+            out.append(ms.value)
+        return out
+
+    def close(self):
+        lib = _lib.load()
+        for arr in (self.begin, self.end):
+            for i in range(self.n):
+                lib.capdec_event_destroy(arr[i])
+        self.n = 0
+
+
+def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=False, resolve_dirty=True, probe=None,
+                  to_cpu=True):
     """Greedy decode on the GPU.  enc [B,S,E] fp32.  Returns (ids int64 [B,max_length] padded with -1, lengths
-    int32 [B]) as CPU tensors, plus the number of rows that went through the exact path."""
+    int32 [B], number of rows that went through the exact path).  ids/lengths are CPU tensors unless
+    ``to_cpu=False`` (then they stay on the device, e.g. for a cross-rank gather)."""
     lib = _lib.load()
     if not enc.is_cuda or enc.dtype != torch.float32:
         raise RuntimeError("capdec: enc must be an fp32 tensor on the GPU (HIP); there is no CPU path")
@@ -68,38 +104,42 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
     if E != ref.E:
         raise RuntimeError(f"capdec: encoder width {E} != embed size {ref.E}")
     dev = enc.device
-    if B == 0:
-        return torch.empty((0, max_length), dtype=torch.int64), torch.empty((0,), dtype=torch.int32), 0
     out_ids = torch.empty((B, max_length), dtype=torch.int64, device=dev)
     out_len = torch.empty((B,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        if exact:
-            _exact(lib, ref, enc, max_length, sos, eos, out_ids, out_len)
-            return out_ids.cpu(), out_len.cpu(), B
-        dirty = torch.empty((B,), dtype=torch.int32, device=dev)
-        nbytes = lib.capdec_tf_decode_workspace_bytes(ctypes.byref(ref.c), B, S, max_length)
-        if nbytes == 0 and B > 0:
-            raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
-        ws = _workspace(nbytes, dev)
-        flags = _lib.DECODE_NO_S1_SHORTCUT if no_s1_shortcut else 0
-        _lib.check(lib.capdec_tf_greedy_decode(ctypes.byref(ref.c), enc.data_ptr(), B, S, max_length, sos, eos, flags,
-                                               ws.data_ptr(), ws.numel(), out_ids.data_ptr(), out_len.data_ptr(),
-                                               dirty.data_ptr(), _stream()), "capdec_tf_greedy_decode")
-        ids_c, len_c, dirty_c = out_ids.cpu(), out_len.cpu(), dirty.cpu()   # the one host sync of the decode
-        n_dirty = 0
-        if resolve_dirty:
-            rows = torch.nonzero(dirty_c, as_tuple=False).flatten()
-            n_dirty = int(rows.numel())
-            if n_dirty:
-                # a generated <PAD> makes that position's activations depend on the current length
-                # (transformer.py:117-123: PAD masks the query row); redo those rows on the exact path
-                sub = enc.index_select(0, rows.to(dev)).contiguous()
-                ids2 = torch.empty((n_dirty, max_length), dtype=torch.int64, device=dev)
-                len2 = torch.empty((n_dirty,), dtype=torch.int32, device=dev)
-                _exact(lib, ref, sub, max_length, sos, eos, ids2, len2)
-                ids_c[rows] = ids2.cpu()
-                len_c[rows] = len2.cpu()
-    return ids_c, len_c, n_dirty
+    n_dirty = 0
+    if B > 0:
+        with torch.cuda.device(dev):
+            if exact:
+                _exact(lib, ref, enc, max_length, sos, eos, out_ids, out_len)
+                n_dirty = B
+            else:
+                dirty = torch.empty((B,), dtype=torch.int32, device=dev)
+                nbytes = lib.capdec_tf_decode_workspace_bytes(ctypes.byref(ref.c), B, S, max_length)
+                if nbytes == 0:
+                    raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
+                ws = _workspace(nbytes, dev)
+                flags = _lib.DECODE_NO_S1_SHORTCUT if no_s1_shortcut else 0
+                _lib.check(lib.capdec_tf_greedy_decode(ctypes.byref(ref.c), enc.data_ptr(), B, S, max_length, sos, eos,
+                                                       flags, ws.data_ptr(), ws.numel(), out_ids.data_ptr(),
+                                                       out_len.data_ptr(), dirty.data_ptr(),
+                                                       ctypes.byref(probe.c) if probe else None, _stream()),
+                           "capdec_tf_greedy_decode")
+                if resolve_dirty:
+                    rows = torch.nonzero(dirty.cpu(), as_tuple=False).flatten()   # the one host sync of the decode
+                    n_dirty = int(rows.numel())
+                    if n_dirty:
+                        # a generated <PAD> makes that position's activations depend on the current length
+                        # (transformer.py:117-123: PAD masks the query row); redo those rows on the exact path
+                        rows = rows.to(dev)
+                        sub = enc.index_select(0, rows).contiguous()
+                        ids2 = torch.empty((n_dirty, max_length), dtype=torch.int64, device=dev)
+                        len2 = torch.empty((n_dirty,), dtype=torch.int32, device=dev)
+                        _exact(lib, ref, sub, max_length, sos, eos, ids2, len2)
+                        out_ids.index_copy_(0, rows, ids2)
+                        out_len.index_copy_(0, rows, len2)
+    if to_cpu:
+        return out_ids.cpu(), out_len.cpu(), n_dirty
+    return out_ids, out_len, n_dirty
 
 
 def _exact(lib, ref, enc, max_length, sos, eos, out_ids, out_len):

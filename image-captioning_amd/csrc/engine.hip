@@ -200,9 +200,27 @@ size_t capdec_tf_decode_workspace_bytes(const capdec_tf_model* m, int B, int S, 
     return carve_decode(m, B, S, max_len, nullptr, nullptr);
 }
 
+int capdec_event_create(void** ev) {
+    CAPDEC_REQUIRE(ev);
+    hipEvent_t e;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return (int)rc;
+    *ev = (void*)e;
+    return 0;
+}
+int capdec_event_destroy(void* ev) { return ev ? (int)hipEventDestroy((hipEvent_t)ev) : 0; }
+int capdec_event_record(void* ev, void* stream) {
+    CAPDEC_REQUIRE(ev);
+    return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+}
+int capdec_event_elapsed_ms(void* begin, void* end, float* ms) {
+    CAPDEC_REQUIRE(begin && end && ms);
+    return (int)hipEventElapsedTime(ms, (hipEvent_t)begin, (hipEvent_t)end);
+}
+
 int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, int S, int max_len, int sos, int eos,
                             int flags, void* workspace, size_t workspace_bytes, int64_t* out_ids, int32_t* out_len,
-                            int32_t* out_dirty, void* stream) {
+                            int32_t* out_dirty, const capdec_probe* probe, void* stream) {
     CAPDEC_TRY(check_model(m));
     CAPDEC_REQUIRE(enc && out_ids && out_len && B >= 0 && S >= 1 && S <= 2048 && max_len >= 1);
     CAPDEC_REQUIRE(max_len <= m->max_pos);           // the reference's pe buffer has max_pos rows
@@ -269,7 +287,10 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
             CAPDEC_TRY(capdec_add_layernorm(w.y, nullptr, 1, ly.n3_g, ly.n3_b, 1e-5f, B, E, w.x, nullptr, nullptr,
                                             stream));
         }
+        const bool probed = probe && t < probe->n;
+        if (probed) CAPDEC_TRY((int)hipEventRecord((hipEvent_t)probe->begin[t], s));
         CAPDEC_TRY(capdec_vocab_argmax_partial(w.x, E, m->fc2_w, m->fc2_b, B, V, E, w.pval, w.pidx, stream));
+        if (probed) CAPDEC_TRY((int)hipEventRecord((hipEvent_t)probe->end[t], s));
         const bool last = (t + 1 == max_len);
         hipLaunchKernelGGL(greedy_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
                            eos, w.tok, ldtok, w.done, out_ids, out_len, out_dirty, m->emb, m->pe, E, V,

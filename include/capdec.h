@@ -163,10 +163,24 @@ size_t capdec_tf_decode_workspace_bytes(const capdec_tf_model* m, int B, int S, 
  * are always enqueued (there is no host sync to test the reference's all-rows-done early exit, which has no
  * visible effect on the outputs).  With S == 1 the softmax over the single memory row is exactly 1, so the
  * cross-attention block reduces to one vector per sample and layer that is computed once (bit-identical). */
+/* Optional timing probe: HIP events recorded on `stream` right before / after the vocabulary-projection
+ * kernel of decode step t, for t < n.  Events are created with capdec_event_create; read them with
+ * capdec_event_elapsed_ms after the stream has been synchronised.  Measurement plumbing only: it has no
+ * counterpart in the reference. */
+typedef struct capdec_probe {
+    void** begin;   /* host array of n hipEvent_t */
+    void** end;     /* host array of n hipEvent_t */
+    int32_t n;
+} capdec_probe;
+int capdec_event_create(void** ev);
+int capdec_event_destroy(void* ev);
+int capdec_event_record(void* ev, void* stream);
+int capdec_event_elapsed_ms(void* begin, void* end, float* ms);
+
 #define CAPDEC_DECODE_NO_S1_SHORTCUT 1   /* run the general cross-attention kernels even when S == 1 */
 int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, int S, int max_len, int sos, int eos,
                             int flags, void* workspace, size_t workspace_bytes, int64_t* out_ids, int32_t* out_len,
-                            int32_t* out_dirty, void* stream);
+                            int32_t* out_dirty, const capdec_probe* probe /*nullable*/, void* stream);
 
 /* Exact full-prefix greedy decode (re-runs the whole prefix every step, as the reference does).
  * Same outputs; used for rows flagged dirty above and as an in-library cross-check. */
