@@ -5,13 +5,15 @@ raises.  Build the library first with ``python image-captioning_amd/capdec/_buil
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcapdec.so")
 
 ABI_VERSION = 1
 GEMM_RELU = 1
+GEMM_TP = 2
+GEMM_TQ = 4
 DECODE_NO_S1_SHORTCUT = 1
 
 
@@ -20,6 +22,11 @@ class GemmGroup(Structure):
                 ("scale_j", c_void_p), ("shift_j", c_void_p), ("R", c_void_p),
                 ("ldp", c_int64), ("ldq", c_int64), ("ldci", c_int64), ("ldcj", c_int64), ("ldri", c_int64),
                 ("ldrj", c_int64), ("I", c_int32), ("J", c_int32)]
+
+
+class GemmExtra(Structure):
+    _fields_ = [("mask", c_void_p), ("ldm", c_int64), ("lse", c_void_p), ("tgt", c_void_p), ("gscale", c_void_p),
+                ("ignore_index", c_int64)]
 
 
 class AttnW(Structure):
@@ -61,6 +68,18 @@ _SIGNATURES = {
     "capdec_attention": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P]),
     "capdec_lstm_step": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P, _P]),
+    "capdec_gemm_ex": (c_int, [POINTER(GemmGroup), c_int, c_int, c_int, POINTER(GemmExtra), _P]),
+    "capdec_dropout": (c_int, [_P, c_int64, c_float, c_uint64, _P, _P]),
+    "capdec_add_layernorm_train": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
+    "capdec_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
+    "capdec_colsum": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
+    "capdec_embed_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    "capdec_bn_train_backward": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "capdec_attention_bwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, _P,
+                                     _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
+    "capdec_loss_finish": (c_int, [_P, _P, _P, _P]),
+    "capdec_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "capdec_bn_fold": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
     "capdec_bn_train_forward": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "capdec_tf_decode_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int]),

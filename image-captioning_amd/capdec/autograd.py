@@ -1,0 +1,276 @@
+"""Explicit forward / backward of the caption decoders on the HIP kernels, plus thin
+``torch.autograd.Function`` wrappers so that ``loss.backward()`` in an unmodified training loop
+(reference train.py:252-262) lands in these kernels.
+
+No ATen arithmetic is used: torch only allocates tensors.  Every saved activation is a plain tensor held
+in a ``Tape``; gradients of parameters are written into ``grads[name]`` tensors that the caller may
+pre-allocate (e.g. as views of one flat buffer for a single RCCL all-reduce and a fused Adam step).
+"""
+import torch
+
+from . import ops
+
+_SITE = 0x51ED2701  # odd stride between the dropout seeds of different sites
+
+
+def draw_seed():
+    """A fresh 62-bit dropout seed from torch's CPU generator (so torch.manual_seed makes runs repeatable)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class Tape:
+    pass
+
+
+def _new(grads, name, like):
+    """Gradient buffer for parameter ``name``: the caller's (pre-zeroed) tensor, or a fresh zero tensor."""
+    g = grads.get(name)
+    if g is None:
+        g = torch.zeros_like(like)
+        grads[name] = g
+    return g
+
+
+def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None):
+    """Backward of y = x W^T + b: fills grads[prefix.weight/.bias]; returns dX (added onto ``accum`` if given)."""
+    ops.linear_wgrad(dy, x, out=_new(grads, prefix + ".weight", lin.weight))
+    if lin.bias is not None:
+        ops.colsum(dy, _new(grads, prefix + ".bias", lin.bias))
+    if need_dx:
+        return ops.linear_dgrad(dy, lin.weight, mask=mask, accum=accum)
+    return None
+
+
+# ---------------------------------------------------------------------------------------------
+# Transformer decoder stack
+# ---------------------------------------------------------------------------------------------
+def tf_forward(dec, enc, ids, p, seed):
+    """Teacher-forced decoder stack (reference transformer.py:125-132) keeping what the backward needs.
+    enc [B,S,E] fp32, ids [B,T] int64.  Returns (x [B*T,E] post-LN output of the last layer, tape)."""
+    B, S, E = enc.shape
+    T = ids.shape[1]
+    M, H = B * T, dec.num_heads
+    t = Tape()
+    t.B, t.S, t.T, t.E, t.H, t.p, t.seed = B, S, T, E, H, p, seed
+    t.ids = ids.contiguous()
+    t.ids32 = t.ids.to(torch.int32)
+    t.enc = enc.reshape(B * S, E)
+    pe = dec.positional_encoding.pe[0]
+    if T > pe.shape[0]:
+        raise RuntimeError(f"capdec: sequence length {T} exceeds the positional-encoding buffer ({pe.shape[0]})")
+    x = ops.embed_pe(t.ids, dec.decoder_embedding.weight, pe)
+    if p > 0:
+        x = ops.dropout(x, p, seed)
+    t.layers = []
+    for l, ly in enumerate(dec.decoder_layers):
+        c = Tape()
+        sd = seed + (3 * l + 1) * _SITE
+        c.x = x
+        sa, ca, ff = ly.self_attn, ly.cross_attn, ly.feed_forward
+        qkv = torch.empty((3, M, E), device=x.device, dtype=torch.float32)
+        ops.gemm_groups([dict(P=x, Q=sa.W_q.weight, C=qkv[0], bias_j=sa.W_q.bias),
+                         dict(P=x, Q=sa.W_k.weight, C=qkv[1], bias_j=sa.W_k.bias),
+                         dict(P=x, Q=sa.W_v.weight, C=qkv[2], bias_j=sa.W_v.bias)], E)
+        c.qkv = qkv
+        c.ao, c.lse = ops.attention(qkv[0], qkv[1], qkv[2], B, H, T, T, causal=True, ids32=t.ids32, want_lse=True)
+        a = ops.linear(c.ao, sa.W_o.weight, sa.W_o.bias)
+        c.x1, c.s1, c.m1, c.r1 = ops.add_layernorm_train(a, x, ly.norm1.weight, ly.norm1.bias, p, sd)
+        c.q2 = ops.linear(c.x1, ca.W_q.weight, ca.W_q.bias)
+        kv2 = torch.empty((2, B * S, E), device=x.device, dtype=torch.float32)
+        ops.gemm_groups([dict(P=t.enc, Q=ca.W_k.weight, C=kv2[0], bias_j=ca.W_k.bias),
+                         dict(P=t.enc, Q=ca.W_v.weight, C=kv2[1], bias_j=ca.W_v.bias)], E)
+        c.kv2 = kv2
+        c.ao2, c.lse2 = ops.attention(c.q2, kv2[0], kv2[1], B, H, T, S, want_lse=True)
+        a2 = ops.linear(c.ao2, ca.W_o.weight, ca.W_o.bias)
+        c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(a2, c.x1, ly.norm2.weight, ly.norm2.bias, p, sd + _SITE)
+        c.h = ops.linear(c.x2, ff.fc1.weight, ff.fc1.bias, relu=True)
+        f = ops.linear(c.h, ff.fc2.weight, ff.fc2.bias)
+        x, c.s3, c.m3, c.r3 = ops.add_layernorm_train(f, c.x2, ly.norm3.weight, ly.norm3.bias, p, sd + 2 * _SITE)
+        t.layers.append(c)
+    t.out = x
+    return x, t
+
+
+def tf_backward(dec, t, dx, grads, need_denc=True):
+    """Backward of ``tf_forward``.  dx [B*T,E].  Fills ``grads`` (keys = names under ``dec``); returns denc
+    [B,S,E] (or None)."""
+    B, S, T, E, H, p = t.B, t.S, t.T, t.E, t.H, t.p
+    denc = torch.zeros((B * S, E), device=dx.device, dtype=torch.float32) if need_denc else None
+    for l in range(len(t.layers) - 1, -1, -1):
+        ly, c = dec.decoder_layers[l], t.layers[l]
+        pre = f"decoder_layers.{l}."
+        sd = t.seed + (3 * l + 1) * _SITE
+        sa, ca, ff = ly.self_attn, ly.cross_attn, ly.feed_forward
+        # x3 = LN3(x2 + drop(f)),  f = relu(x2 W1^T + b1) W2^T + b2
+        d_x2, d_f = ops.layernorm_bwd(dx, c.s3, c.m3, c.r3, ly.norm3.weight, p, sd + 2 * _SITE,
+                                      _new(grads, pre + "norm3.weight", ly.norm3.weight),
+                                      _new(grads, pre + "norm3.bias", ly.norm3.bias))
+        dh = _lin_bwd(grads, pre + "feed_forward.fc2", ff.fc2, d_f, c.h, mask=c.h)       # ReLU backward fused
+        _lin_bwd(grads, pre + "feed_forward.fc1", ff.fc1, dh, c.x2, accum=d_x2)
+        # x2 = LN2(x1 + drop(a2)),  a2 = attn(x1 Wq, enc Wk, enc Wv) Wo
+        d_x1, d_a2 = ops.layernorm_bwd(d_x2, c.s2, c.m2, c.r2, ly.norm2.weight, p, sd + _SITE,
+                                       _new(grads, pre + "norm2.weight", ly.norm2.weight),
+                                       _new(grads, pre + "norm2.bias", ly.norm2.bias))
+        d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2)
+        dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S)
+        _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1)
+        _lin_bwd(grads, pre + "cross_attn.W_k", ca.W_k, dk2, t.enc, need_dx=need_denc, accum=denc)
+        _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, dv2, t.enc, need_dx=need_denc, accum=denc)
+        # x1 = LN1(x + drop(a)),  a = attn(x Wq, x Wk, x Wv; causal, PAD rows) Wo
+        d_x, d_a = ops.layernorm_bwd(d_x1, c.s1, c.m1, c.r1, ly.norm1.weight, p, sd,
+                                     _new(grads, pre + "norm1.weight", ly.norm1.weight),
+                                     _new(grads, pre + "norm1.bias", ly.norm1.bias))
+        d_ao = _lin_bwd(grads, pre + "self_attn.W_o", sa.W_o, d_a, c.ao)
+        dq, dk, dv = ops.attention_bwd(c.qkv[0], c.qkv[1], c.qkv[2], d_ao, c.lse, B, H, T, T, causal=True,
+                                       ids32=t.ids32)
+        _lin_bwd(grads, pre + "self_attn.W_q", sa.W_q, dq, c.x, accum=d_x)
+        _lin_bwd(grads, pre + "self_attn.W_k", sa.W_k, dk, c.x, accum=d_x)
+        _lin_bwd(grads, pre + "self_attn.W_v", sa.W_v, dv, c.x, accum=d_x)
+        dx = d_x
+    if p > 0:
+        dx = ops.dropout(dx, p, t.seed)
+    ops.embed_bwd(t.ids.view(-1), dx, _new(grads, "decoder_embedding.weight", dec.decoder_embedding.weight))
+    return denc.view(B, S, E) if need_denc else None
+
+
+def vocab_logits_bwd(dec, x, dlogits, grads):
+    """Backward of logits = x fc2^T + b given dlogits [M,V]; returns dx."""
+    return _lin_bwd(grads, "fc2", dec.fc2, dlogits, x)
+
+
+def vocab_loss(dec, x, targets, ignore_index=0):
+    """Fused projection + CrossEntropyLoss(ignore_index) (reference train.py:216,254-256) without logits.
+    Returns (loss [1] device tensor, saved state for ``vocab_loss_bwd``)."""
+    lse, nll, sums = ops.vocab_nll(x, dec.fc2.weight, dec.fc2.bias, targets.reshape(-1), ignore_index)
+    loss, gscale = ops.loss_finish(sums)
+    return loss, (lse, gscale, targets.reshape(-1).contiguous(), ignore_index)
+
+
+def vocab_loss_bwd(dec, x, saved, grads):
+    """d(loss)/dx; the [M,V] softmax gradient is recomputed tile-wise from the projection and the saved
+    log-sum-exp (one transient buffer), then contracted with fc2 and x."""
+    lse, gscale, targets, ignore_index = saved
+    dlogits = ops.softmax_grad_logits(x, dec.fc2.weight, dec.fc2.bias, lse, targets, gscale, ignore_index)
+    return _lin_bwd(grads, "fc2", dec.fc2, dlogits, x)
+
+
+# ---------------------------------------------------------------------------------------------
+# feature heads: Linear -> dropout -> BatchNorm1d (training statistics)
+# ---------------------------------------------------------------------------------------------
+def head_forward(model, parts, x, dropout_first, seed):
+    """Training-mode head; returns (y [B, n*E], tape).  Updates the BatchNorm running buffers in place."""
+    bn = model.batchnorm
+    p = model.dropout.p
+    t = Tape()
+    t.parts, t.p, t.seed, t.dropout_first = parts, p, seed, dropout_first
+    xin = x.contiguous()
+    if dropout_first and p > 0:
+        xin = ops.dropout(xin, p, seed)
+    t.xin = xin
+    B = x.shape[0]
+    E = parts[0][0].weight.shape[0]
+    z = torch.empty((B, len(parts) * E), device=x.device, dtype=torch.float32)
+    for n, (fc, lo, hi) in enumerate(parts):
+        ops.gemm_groups([dict(P=xin[:, lo:hi], Q=fc.weight, C=z[:, n * E:(n + 1) * E], bias_j=fc.bias)], hi - lo)
+    if not dropout_first and p > 0:
+        z = ops.dropout(z, p, seed)
+    t.z = z
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    y, t.mean, t.rstd = ops.bn_train_forward(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps)
+    bn.num_batches_tracked += 1
+    return y, t
+
+
+def head_backward(model, names, t, dy, grads):
+    """names[n] is the attribute name of parts[n][0] (e.g. 'fc1', 'fc_vit', 'fc_cnn')."""
+    bn = model.batchnorm
+    dz = ops.bn_train_backward(dy.contiguous(), t.z, bn.weight, t.mean, t.rstd,
+                               _new(grads, "batchnorm.weight", bn.weight), _new(grads, "batchnorm.bias", bn.bias))
+    if not t.dropout_first and t.p > 0:
+        dz = ops.dropout(dz, t.p, t.seed)
+    E = t.parts[0][0].weight.shape[0]
+    for n, (fc, lo, hi) in enumerate(t.parts):
+        _lin_bwd(grads, names[n], fc, dz[:, n * E:(n + 1) * E], t.xin[:, lo:hi], need_dx=False)
+
+
+# ---------------------------------------------------------------------------------------------
+# torch.autograd bridges (drop-in use: model(imgs, captions) -> logits; loss.backward())
+# ---------------------------------------------------------------------------------------------
+def _decoder_params(dec):
+    """(name, tensor) of every parameter of the decoder proper, in a fixed order."""
+    out = []
+    for name, prm in dec.named_parameters():
+        if name.startswith("decoder_layers.") or name.startswith("fc2.") or name.startswith("decoder_embedding."):
+            out.append((name, prm))
+    return out
+
+
+class _DecoderLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dec, captions, enc, *params):
+        p = dec.dropout.p if dec.training else 0.0
+        x, tape = tf_forward(dec, enc.detach(), captions, p, draw_seed() if p > 0 else 0)
+        B, T = captions.shape
+        logits = ops.linear(x, dec.fc2.weight, dec.fc2.bias).view(B, T, -1)
+        ctx.dec, ctx.tape = dec, tape
+        ctx.need_denc = enc.requires_grad
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        dec, tape = ctx.dec, ctx.tape
+        grads = {}
+        V = dlogits.shape[-1]
+        dx = vocab_logits_bwd(dec, tape.out, dlogits.contiguous().view(-1, V), grads)
+        denc = tf_backward(dec, tape, dx, grads, need_denc=ctx.need_denc)
+        return (None, None, denc) + tuple(grads.get(n) for n, _ in _decoder_params(dec))
+
+
+def decoder_forward(dec, enc_output, captions, take_last=False):
+    if take_last:
+        raise NotImplementedError("take_last is an inference option (greedy decode); call it under torch.no_grad()")
+    if not enc_output.is_cuda or not captions.is_cuda:
+        raise RuntimeError("capdec: inputs must live on the GPU (HIP); there is no CPU path")
+    return _DecoderLogitsFn.apply(dec, captions, enc_output, *[p for _, p in _decoder_params(dec)])
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, parts, names, dropout_first, x, *params):
+        p = model.dropout.p
+        y, tape = head_forward(model, parts, x.detach(), dropout_first, draw_seed() if p > 0 else 0)
+        ctx.model, ctx.tape, ctx.names = model, tape, names
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        grads = {}
+        head_backward(ctx.model, ctx.names, ctx.tape, dy, grads)
+        order = []
+        for n in ctx.names:
+            fc = getattr(ctx.model, n)
+            order.append(grads.get(n + ".weight"))
+            if fc.bias is not None:
+                order.append(grads.get(n + ".bias"))
+        order += [grads.get("batchnorm.weight"), grads.get("batchnorm.bias")]
+        return (None, None, None, None, None) + tuple(order)
+
+
+def head_train(model, parts, x, dropout_first):
+    names = []
+    for fc, _, _ in parts:
+        names.append(next(n for n, m in model.named_children() if m is fc))
+    params = []
+    for n in names:
+        fc = getattr(model, n)
+        params.append(fc.weight)
+        if fc.bias is not None:
+            params.append(fc.bias)
+    params += [model.batchnorm.weight, model.batchnorm.bias]
+    if x.requires_grad:
+        raise NotImplementedError("capdec: gradients w.r.t. the backbone features are not part of the hot path")
+    return _HeadFn.apply(model, parts, names, dropout_first, x, *params)
+
+
+def decoder_rnn_forward(rnn, features, captions):
+    raise NotImplementedError("CNN-RNN training (LSTM backward) is not built yet; inference and greedy decode are")

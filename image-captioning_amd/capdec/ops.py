@@ -230,3 +230,169 @@ def vocab_nll(x, W, b, targets, ignore_index=0):
                                        lse.data_ptr(), nll.data_ptr(), sums.data_ptr(), _stream()),
                "capdec_nll_finalize")
     return lse, nll, sums
+
+
+# ---------------------------------------------------------------------------------------------
+# training-side ops
+# ---------------------------------------------------------------------------------------------
+def gemm_raw(P, Q, C, I, J, K, ldp, ldq, flags=0, bias_j=None, R=None, mask=None, lse=None, tgt=None, gscale=None,
+             ignore_index=0):
+    """Single-group contraction with explicit layout: see capdec_gemm_ex in capdec.h."""
+    lib = _lib.load()
+    g = (GemmGroup * 1)()
+    g[0].P, g[0].Q, g[0].C = _chk(P).data_ptr(), _chk(Q).data_ptr(), _chk(C).data_ptr()
+    g[0].ldp, g[0].ldq, g[0].ldci, g[0].ldcj, g[0].I, g[0].J = ldp, ldq, _row_stride(C, "C"), 1, I, J
+    if C.shape[0] != I or C.shape[1] != J:
+        raise RuntimeError(f"capdec gemm_raw: C {tuple(C.shape)} != ({I},{J})")
+    g[0].bias_j = _ptr(bias_j)
+    if R is not None:
+        g[0].R, g[0].ldri, g[0].ldrj = _chk(R).data_ptr(), _row_stride(R, "R"), 1
+    ex = _lib.GemmExtra()
+    if mask is not None:
+        ex.mask, ex.ldm = _chk(mask).data_ptr(), _row_stride(mask, "mask")
+    if lse is not None:
+        ex.lse, ex.tgt, ex.gscale, ex.ignore_index = (_chk(lse).data_ptr(), _chk(tgt, torch.int64).data_ptr(),
+                                                       _chk(gscale).data_ptr(), ignore_index)
+    _lib.check(lib.capdec_gemm_ex(g, 1, K, flags, byref(ex), _stream()), "capdec_gemm_ex")
+    return C
+
+
+def linear_dgrad(dy, W, mask=None, accum=None):
+    """dX = dY W  (dY [M,N], W [N,K]); zeroed where mask <= 0; added onto ``accum`` in place when given."""
+    M, N = dy.shape
+    K = W.shape[1]
+    out = accum if accum is not None else torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    return gemm_raw(dy, W, out, M, K, N, _row_stride(dy, "dy"), _row_stride(W, "W"), _lib.GEMM_TQ, R=accum, mask=mask)
+
+
+def linear_wgrad(dy, x, out=None):
+    """dW = dY^T X  (dY [M,N], X [M,K]) -> [N,K]"""
+    M, N = dy.shape
+    K = x.shape[1]
+    if out is None:
+        out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
+    return gemm_raw(dy, x, out, N, K, M, _row_stride(dy, "dy"), _row_stride(x, "x"), _lib.GEMM_TP | _lib.GEMM_TQ)
+
+
+def colsum(x, out):
+    """out[j] += sum_i x[i,j]"""
+    lib = _lib.load()
+    M, N = x.shape
+    _lib.check(lib.capdec_colsum(_chk(x).data_ptr(), _row_stride(x, "x"), M, N, _chk(out).data_ptr(), _stream()),
+               "capdec_colsum")
+    return out
+
+
+def dropout(x, p, seed, out=None):
+    lib = _lib.load()
+    if not x.is_contiguous():
+        raise RuntimeError("capdec dropout: x must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.capdec_dropout(_chk(x).data_ptr(), x.numel(), p, seed, out.data_ptr(), _stream()), "capdec_dropout")
+    return out
+
+
+def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5):
+    """s = add + dropout(x); y = LN(s).  Returns (y, s, mean, rstd)."""
+    lib = _lib.load()
+    M, E = x.shape
+    y = torch.empty((M, E), device=x.device, dtype=torch.float32)
+    s = torch.empty_like(y)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    if not x.is_contiguous() or not add.is_contiguous():
+        raise RuntimeError("capdec add_layernorm_train: operands must be contiguous")
+    _lib.check(lib.capdec_add_layernorm_train(_chk(x).data_ptr(), _chk(add).data_ptr(), _chk(gamma).data_ptr(),
+                                              _chk(beta).data_ptr(), eps, M, E, p, seed, y.data_ptr(), s.data_ptr(),
+                                              mean.data_ptr(), rstd.data_ptr(), _stream()),
+               "capdec_add_layernorm_train")
+    return y, s, mean, rstd
+
+
+def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta):
+    """Returns (d_add, d_x); dgamma/dbeta are accumulated."""
+    lib = _lib.load()
+    M, E = dy.shape
+    if not dy.is_contiguous():
+        raise RuntimeError("capdec layernorm_bwd: dy must be contiguous")
+    d_add = torch.empty((M, E), device=dy.device, dtype=torch.float32)
+    d_x = torch.empty_like(d_add) if p > 0 else None
+    _lib.check(lib.capdec_layernorm_bwd(_chk(dy).data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                        _chk(gamma).data_ptr(), M, E, p, seed, d_add.data_ptr(), _ptr(d_x),
+                                        _chk(dgamma).data_ptr(), _chk(dbeta).data_ptr(), _stream()),
+               "capdec_layernorm_bwd")
+    return d_add, (d_x if p > 0 else d_add)
+
+
+def attention_bwd(q, k, v, dout, lse, B, H, Tq, Tk, causal=False, ids32=None, dq=None, dk=None, dv=None):
+    """Backward of ``attention``; q/dout [B*Tq,E], k/v [B*Tk,E] 2-D views.  Returns (dq, dk, dv)."""
+    lib = _lib.load()
+    E = q.shape[1]
+    dkh = E // H
+    dev = q.device
+    if dq is None:
+        dq = torch.empty((B * Tq, E), device=dev, dtype=torch.float32)
+    if dk is None:
+        dk = torch.empty((B * Tk, E), device=dev, dtype=torch.float32)
+    if dv is None:
+        dv = torch.empty((B * Tk, E), device=dev, dtype=torch.float32)
+    dsum = torch.empty((B, H, Tq), device=dev, dtype=torch.float32)
+    ldid = 0
+    if ids32 is not None:
+        ldid = ids32.stride(0) if B > 1 else max(ids32.shape[1], Tq)
+    ldk, ldv, lddk, lddv = (_row_stride(t, "kv") for t in (k, v, dk, dv))
+    _lib.check(lib.capdec_attention_bwd(_chk(q).data_ptr(), _row_stride(q, "q"), _chk(k).data_ptr(), ldk, ldk * Tk,
+                                        _chk(v).data_ptr(), ldv, ldv * Tk, _chk(dout).data_ptr(),
+                                        _row_stride(dout, "dout"), _chk(lse).data_ptr(), dsum.data_ptr(),
+                                        dq.data_ptr(), _row_stride(dq, "dq"), dk.data_ptr(), lddk, lddk * Tk,
+                                        dv.data_ptr(), lddv, lddv * Tk, B, H, Tq, Tk, dkh, 1 if causal else 0, 0,
+                                        _ptr(ids32), ldid, _stream()), "capdec_attention_bwd")
+    return dq, dk, dv
+
+
+def embed_bwd(ids, dx, demb):
+    lib = _lib.load()
+    ids = ids.contiguous()
+    rows, E = dx.shape
+    _lib.check(lib.capdec_embed_bwd(_chk(ids, torch.int64).data_ptr(), _chk(dx).data_ptr(), rows, E, demb.shape[0],
+                                    _chk(demb).data_ptr(), _stream()), "capdec_embed_bwd")
+    return demb
+
+
+def bn_train_backward(dy, x, gamma, mean, rstd, dgamma, dbeta):
+    lib = _lib.load()
+    B, C = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(lib.capdec_bn_train_backward(_chk(dy).data_ptr(), _chk(x).data_ptr(), _chk(gamma).data_ptr(),
+                                            mean.data_ptr(), rstd.data_ptr(), B, C, dx.data_ptr(), dgamma.data_ptr(),
+                                            dbeta.data_ptr(), _stream()), "capdec_bn_train_backward")
+    return dx
+
+
+def softmax_grad_logits(x, W, b, lse, targets, gscale, ignore_index=0, out=None):
+    """dlogits = (softmax(x W^T + b) - onehot(targets)) * gscale on counted rows, recomputed from the projection."""
+    M, K = x.shape
+    V = W.shape[0]
+    if out is None:
+        out = torch.empty((M, V), device=x.device, dtype=torch.float32)
+    return gemm_raw(x, W, out, M, V, K, _row_stride(x, "x"), _row_stride(W, "W"), 0, bias_j=b, lse=lse, tgt=targets,
+                    gscale=gscale, ignore_index=ignore_index)
+
+
+def loss_finish(sums):
+    lib = _lib.load()
+    loss = torch.empty(1, device=sums.device, dtype=torch.float32)
+    gscale = torch.empty(1, device=sums.device, dtype=torch.float32)
+    _lib.check(lib.capdec_loss_finish(_chk(sums).data_ptr(), loss.data_ptr(), gscale.data_ptr(), _stream()),
+               "capdec_loss_finish")
+    return loss, gscale
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    lib = _lib.load()
+    for t in (p, g, m, v):
+        if not t.is_contiguous() or t.numel() != p.numel():
+            raise RuntimeError("capdec adam_step: flat contiguous buffers of equal length expected")
+    _lib.check(lib.capdec_adam_step(_chk(p).data_ptr(), _chk(g).data_ptr(), _chk(m).data_ptr(), _chk(v).data_ptr(),
+                                    p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()), "capdec_adam_step")

@@ -54,4 +54,5 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 }
 
 // internal launchers shared between translation units (all return 0 / CAPDEC_E* / hipError_t)
-int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, hipStream_t s);
+int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, hipStream_t s,
+                       const capdec_gemm_extra* extra = nullptr);

@@ -18,50 +18,114 @@
 namespace {
 
 constexpr int BK = 32;    // k extent of one staged tile
-constexpr int LDK = 36;   // padded LDS row stride in floats (144 B)
+constexpr int LDK = 36;   // padded LDS row stride in floats (144 B) of a k-contiguous operand tile
 
 struct GemmKArgs {
     capdec_gemm_group g[4];
     int K;
     int flags;
+    capdec_gemm_extra x;
 };
 
 template <int WI, int WJ>
 constexpr int lds_floats() { return 2 * (64 * WI + 64 * WJ) * LDK; }
 
-template <bool VEC>
-__device__ __forceinline__ f32x4 load_k4(const float* __restrict__ base, int64_t ld, int row, int nrows, int k, int K) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < nrows) {
-        const float* p = base + (int64_t)row * ld + k;
-        if (VEC) {
-            if (k < K) v = *reinterpret_cast<const f32x4*>(p);
+// One operand tile of NX = 64*W rows (the i or j axis) by BK columns (the contraction axis).
+//  T == false: the operand is stored [row][k] (k contiguous).  LDS image [row][LDK]; a lane reads its four
+//              k values with one ds_read_b128.
+//  T == true : the operand is stored [k][row] (row contiguous; the contraction runs over its leading
+//              axis, as in dX = dY W and dW = dY^T X).  LDS image [k][NX+4]; a lane reads its four k values
+//              with four ds_read_b32 (32 consecutive floats per half-wave: conflict-free).
+template <int W, bool VEC, bool T>
+struct Operand {
+    static constexpr int NX = 64 * W;
+    static constexpr int NR = NX / 32;            // float4 per thread per tile
+    static constexpr int LDT = NX + 4;
+    static constexpr int NV = NX / 4;             // float4 per k-row when T
+    static constexpr int KPP = 256 / NV;          // k-rows per pass when T
+    const float* __restrict__ base;
+    int64_t ld;
+    int n, K, x0;
+    float* lds;                                   // 2 buffers
+    f32x4 reg[NR];
+
+    __device__ __forceinline__ void gload(int kt) {
+        const int tid = threadIdx.x;
+        if (!T) {
+            const int lrow = tid >> 3, k = kt * BK + (tid & 7) * 4;
+#pragma unroll
+            for (int p = 0; p < NR; ++p) {
+                const int row = x0 + lrow + 32 * p;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < n) {
+                    const float* q = base + (int64_t)row * ld + k;
+                    if (VEC) {
+                        if (k < K) v = *reinterpret_cast<const f32x4*>(q);
+                    } else {
+                        if (k + 0 < K) v[0] = q[0];
+                        if (k + 1 < K) v[1] = q[1];
+                        if (k + 2 < K) v[2] = q[2];
+                        if (k + 3 < K) v[3] = q[3];
+                    }
+                }
+                reg[p] = v;
+            }
         } else {
-            if (k + 0 < K) v[0] = p[0];
-            if (k + 1 < K) v[1] = p[1];
-            if (k + 2 < K) v[2] = p[2];
-            if (k + 3 < K) v[3] = p[3];
+            const int iv = tid % NV, kr = tid / NV;
+            const int row = x0 + 4 * iv;
+#pragma unroll
+            for (int p = 0; p < NR; ++p) {
+                const int k = kt * BK + kr + KPP * p;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < K) {
+                    const float* q = base + (int64_t)k * ld + row;
+                    if (VEC && row + 3 < n) {
+                        v = *reinterpret_cast<const f32x4*>(q);
+                    } else {
+                        if (row + 0 < n) v[0] = q[0];
+                        if (row + 1 < n) v[1] = q[1];
+                        if (row + 2 < n) v[2] = q[2];
+                        if (row + 3 < n) v[3] = q[3];
+                    }
+                }
+                reg[p] = v;
+            }
         }
     }
-    return v;
-}
+    __device__ __forceinline__ void lstore(int buf) {
+        const int tid = threadIdx.x;
+        if (!T) {
+            const int lrow = tid >> 3, lk = (tid & 7) * 4;
+#pragma unroll
+            for (int p = 0; p < NR; ++p)
+                *reinterpret_cast<f32x4*>(&lds[(buf * NX + lrow + 32 * p) * LDK + lk]) = reg[p];
+        } else {
+            const int iv = tid % NV, kr = tid / NV;
+#pragma unroll
+            for (int p = 0; p < NR; ++p)
+                *reinterpret_cast<f32x4*>(&lds[(buf * BK + kr + KPP * p) * LDT + 4 * iv]) = reg[p];
+        }
+    }
+    // the four k values {kc*8 + 4h + m} of row (w0 + r) for the lane (r, h)
+    __device__ __forceinline__ f32x4 frag(int buf, int w0, int kc, int r, int h) const {
+        if (!T) return *reinterpret_cast<const f32x4*>(&lds[(buf * NX + w0 + r) * LDK + kc * 8 + 4 * h]);
+        const float* q = &lds[(buf * BK + kc * 8 + 4 * h) * LDT + w0 + r];
+        return f32x4{q[0], q[LDT], q[2 * LDT], q[3 * LDT]};
+    }
+};
 
 // Accumulate the (i0, j0) tile into acc.  Ends with every wave past the last barrier, so the caller
 // may reuse `lds` right away.
-template <int WI, int WJ, bool VEC>
+template <int WI, int WJ, bool VEC, bool TP = false, bool TQ = false>
 __device__ __forceinline__ void mainloop(const float* __restrict__ P, const float* __restrict__ Q, int64_t ldp,
                                          int64_t ldq, int I, int J, int K, int i0, int j0, float* lds,
                                          f32x16 (&acc)[WI][WJ]) {
-    constexpr int BI = 64 * WI, BJ = 64 * WJ;
-    constexpr int NP = BI / 32, NQ = BJ / 32;
-    const int tid = threadIdx.x;
-    const int lrow = tid >> 3, lk = (tid & 7) * 4;
-    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int BI = 64 * WI;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    float* Ps = lds;
-    float* Qs = lds + 2 * BI * LDK;
-    f32x4 pr[NP], qr[NQ];
+    Operand<WI, VEC, TP> op{P, ldp, I, K, i0, lds};
+    Operand<WJ, VEC, TQ> oq{Q, ldq, J, K, j0, lds + 2 * BI * LDK};
 
 #pragma unroll
     for (int ti = 0; ti < WI; ++ti)
@@ -71,39 +135,25 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ P, const floa
             for (int e = 0; e < 16; ++e) acc[ti][tj][e] = 0.f;
 
     const int nk = (K + BK - 1) / BK;
-
-    auto gload = [&](int kt) {
-        const int k = kt * BK + lk;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) pr[p] = load_k4<VEC>(P, ldp, i0 + lrow + 32 * p, I, k, K);
-#pragma unroll
-        for (int p = 0; p < NQ; ++p) qr[p] = load_k4<VEC>(Q, ldq, j0 + lrow + 32 * p, J, k, K);
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-            *reinterpret_cast<f32x4*>(&Ps[(buf * BI + lrow + 32 * p) * LDK + lk]) = pr[p];
-#pragma unroll
-        for (int p = 0; p < NQ; ++p)
-            *reinterpret_cast<f32x4*>(&Qs[(buf * BJ + lrow + 32 * p) * LDK + lk]) = qr[p];
-    };
-
-    gload(0);
-    lstore(0);
+    op.gload(0);
+    oq.gload(0);
+    op.lstore(0);
+    oq.lstore(0);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
-        if (more) gload(kt + 1);
-        const float* pa = &Ps[(cur * BI + wi * 32 * WI + r) * LDK + 4 * h];
-        const float* qa = &Qs[(cur * BJ + wj * 32 * WJ + r) * LDK + 4 * h];
+        if (more) {
+            op.gload(kt + 1);
+            oq.gload(kt + 1);
+        }
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             f32x4 a[WI], b[WJ];
 #pragma unroll
-            for (int ti = 0; ti < WI; ++ti) a[ti] = *reinterpret_cast<const f32x4*>(pa + ti * 32 * LDK + kc * 8);
+            for (int ti = 0; ti < WI; ++ti) a[ti] = op.frag(cur, wi * 32 * WI + ti * 32, kc, r, h);
 #pragma unroll
-            for (int tj = 0; tj < WJ; ++tj) b[tj] = *reinterpret_cast<const f32x4*>(qa + tj * 32 * LDK + kc * 8);
+            for (int tj = 0; tj < WJ; ++tj) b[tj] = oq.frag(cur, wj * 32 * WJ + tj * 32, kc, r, h);
             // lane half h feeds k = kc*8 + 4h + m, so MFMA m sums k in {kc*8+m, kc*8+4+m}
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -113,7 +163,10 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ P, const floa
                     for (int tj = 0; tj < WJ; ++tj)
                         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][m], b[tj][m], acc[ti][tj], 0, 0, 0);
         }
-        if (more) lstore(cur ^ 1);
+        if (more) {
+            op.lstore(cur ^ 1);
+            oq.lstore(cur ^ 1);
+        }
         __syncthreads();
         cur ^= 1;
     }
@@ -122,7 +175,7 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ P, const floa
 // accumulator register e of lane-half h is row (e&3) + 8*(e>>2) + 4*h of the 32x32 tile
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
-template <int WI, int WJ, bool VEC>
+template <int WI, int WJ, bool VEC, bool TP, bool TQ>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const capdec_gemm_group& g = args.g[blockIdx.z];
@@ -130,11 +183,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs args) {
     const int i0 = blockIdx.y * BI, j0 = blockIdx.x * BJ;
     if (i0 >= g.I || j0 >= g.J) return;   // groups of different size share the grid
     f32x16 acc[WI][WJ];
-    mainloop<WI, WJ, VEC>(g.P, g.Q, g.ldp, g.ldq, g.I, g.J, args.K, i0, j0, lds, acc);
+    mainloop<WI, WJ, VEC, TP, TQ>(g.P, g.Q, g.ldp, g.ldq, g.I, g.J, args.K, i0, j0, lds, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
     const bool relu = (args.flags & CAPDEC_GEMM_RELU) != 0;
+    const capdec_gemm_extra& x = args.x;
 #pragma unroll
     for (int tj = 0; tj < WJ; ++tj) {
         const int j = j0 + wj * 32 * WJ + tj * 32 + r;
@@ -152,6 +206,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs args) {
                 if (g.bias_i) v += g.bias_i[i];
                 if (g.scale_j) v = v * sc + sh;
                 if (relu) v = fmaxf(v, 0.f);
+                if (x.lse) {
+                    // d(mean NLL)/d(logit): (softmax - onehot) * gscale on rows with a counted target
+                    const int64_t tg = x.tgt[i];
+                    v = (tg == x.ignore_index) ? 0.f : (expf(v - x.lse[i]) - (tg == (int64_t)j ? 1.f : 0.f)) * x.gscale[0];
+                }
+                if (x.mask && !(x.mask[(int64_t)i * x.ldm + j] > 0.f)) v = 0.f;
                 if (g.R) v += g.R[(int64_t)i * g.ldri + (int64_t)j * g.ldrj];
                 g.C[(int64_t)i * g.ldci + (int64_t)j * g.ldcj] = v;
             }
@@ -316,50 +376,72 @@ bool allow_lds(F* kernel, size_t bytes) {
                                (int)bytes) == hipSuccess;
 }
 
-template <int WI, int WJ>
+template <int WI, int WJ, bool TP, bool TQ>
 int launch_gemm_cfg(const GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hipStream_t s) {
     dim3 grid((maxJ + 64 * WJ - 1) / (64 * WJ), (maxI + 64 * WI - 1) / (64 * WI), ngroups);
     constexpr size_t smem = lds_floats<WI, WJ>() * sizeof(float);
-    static const bool ready = allow_lds(gemm_kernel<WI, WJ, true>, smem) && allow_lds(gemm_kernel<WI, WJ, false>, smem);
+    static const bool ready = allow_lds(gemm_kernel<WI, WJ, true, TP, TQ>, smem) &&
+                              allow_lds(gemm_kernel<WI, WJ, false, TP, TQ>, smem);
     if (!ready) return CAPDEC_EINVAL;
-    if (vec) hipLaunchKernelGGL((gemm_kernel<WI, WJ, true>), grid, dim3(256), smem, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<WI, WJ, false>), grid, dim3(256), smem, s, a);
+    if (vec) hipLaunchKernelGGL((gemm_kernel<WI, WJ, true, TP, TQ>), grid, dim3(256), smem, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<WI, WJ, false, TP, TQ>), grid, dim3(256), smem, s, a);
     CAPDEC_LAUNCH_CHECK();
     return 0;
+}
+
+template <bool TP, bool TQ>
+int launch_gemm_layout(const GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hipStream_t s) {
+    const long tiles128 = (long)((maxI + 127) / 128) * ((maxJ + 127) / 128) * ngroups;
+    if (tiles128 >= 192) return launch_gemm_cfg<2, 2, TP, TQ>(a, ngroups, maxI, maxJ, vec, s);
+    return launch_gemm_cfg<1, 1, TP, TQ>(a, ngroups, maxI, maxJ, vec, s);
 }
 
 constexpr int VOCAB_BI = 128;   // vocabulary ids per tile of the fused projections
 
 }  // namespace
 
-int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, hipStream_t s) {
+int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, hipStream_t s,
+                       const capdec_gemm_extra* extra) {
     CAPDEC_REQUIRE(groups && ngroups >= 1 && ngroups <= 4 && K >= 1);
+    const bool tp = (flags & CAPDEC_GEMM_TP) != 0, tq = (flags & CAPDEC_GEMM_TQ) != 0;
+    CAPDEC_REQUIRE(!(tp && !tq));          // layouts built: (P,Q) = (n,n), (n,t), (t,t)
     GemmKArgs a;
     a.K = K;
     a.flags = flags;
+    a.x = capdec_gemm_extra{};
+    if (extra) {
+        a.x = *extra;
+        CAPDEC_REQUIRE(!a.x.lse || (a.x.tgt && a.x.gscale));
+    }
     int maxI = 0, maxJ = 0;
-    bool vec = (K % 4 == 0);
+    bool vec = true;
     for (int n = 0; n < ngroups; ++n) {
         const capdec_gemm_group& g = groups[n];
         CAPDEC_REQUIRE(g.P && g.Q && g.C && g.I >= 0 && g.J >= 0);
-        CAPDEC_REQUIRE(g.ldp >= K && g.ldq >= K);
+        CAPDEC_REQUIRE(g.ldp >= (tp ? g.I : K) && g.ldq >= (tq ? g.J : K));
         CAPDEC_REQUIRE((g.scale_j == nullptr) == (g.shift_j == nullptr));
         a.g[n] = g;
         if (g.I > maxI) maxI = g.I;
         if (g.J > maxJ) maxJ = g.J;
         vec = vec && capdec_aligned16(g.P) && capdec_aligned16(g.Q) && g.ldp % 4 == 0 && g.ldq % 4 == 0;
     }
+    if (!tp || !tq) vec = vec && (K % 4 == 0);   // a k-contiguous operand is read four k at a time
     for (int n = ngroups; n < 4; ++n) a.g[n] = a.g[0];
     if (maxI == 0 || maxJ == 0) return 0;
-    const long tiles128 = (long)((maxI + 127) / 128) * ((maxJ + 127) / 128) * ngroups;
-    if (tiles128 >= 192) return launch_gemm_cfg<2, 2>(a, ngroups, maxI, maxJ, vec, s);
-    return launch_gemm_cfg<1, 1>(a, ngroups, maxI, maxJ, vec, s);
+    if (tp) return launch_gemm_layout<true, true>(a, ngroups, maxI, maxJ, vec, s);
+    if (tq) return launch_gemm_layout<false, true>(a, ngroups, maxI, maxJ, vec, s);
+    return launch_gemm_layout<false, false>(a, ngroups, maxI, maxJ, vec, s);
 }
 
 extern "C" {
 
 int capdec_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, void* stream) {
-    return capdec_launch_gemm(groups, ngroups, K, flags, (hipStream_t)stream);
+    return capdec_launch_gemm(groups, ngroups, K, flags, (hipStream_t)stream, nullptr);
+}
+
+int capdec_gemm_ex(const capdec_gemm_group* groups, int ngroups, int K, int flags, const capdec_gemm_extra* extra,
+                   void* stream) {
+    return capdec_launch_gemm(groups, ngroups, K, flags, (hipStream_t)stream, extra);
 }
 
 int capdec_vocab_tiles(int V) { return (V + VOCAB_BI - 1) / VOCAB_BI; }

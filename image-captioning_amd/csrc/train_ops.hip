@@ -1,0 +1,561 @@
+// Training-side row kernels for gfx950: dropout, LayerNorm (forward with saved statistics, backward),
+// attention backward, embedding scatter-add, BatchNorm1d backward, column sums for bias gradients, Adam.
+// All are HBM-bound: one 64-lane wavefront per row, 16-byte accesses, shuffle reductions; cross-row
+// reductions (dgamma/dbeta/bias gradients) accumulate per workgroup and finish with float atomics.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// counter-based uniform in [0,1): splitmix64 of (seed, element index); the same (seed, index) gives the
+// same mask in the forward and the backward pass, so masks are never stored
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+    return rng_uniform(seed, idx) >= p ? inv_keep : 0.f;
+}
+
+__global__ void dropout_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed, float* __restrict__ y) {
+    const float inv_keep = 1.0f / (1.0f - p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = x[i] * drop_scale(seed, (uint64_t)i, p, inv_keep);
+}
+
+// ---- LayerNorm forward for training: s = add + dropout(x); y = LN(s) ---------------------------------
+constexpr int LN_MAXV = 8;
+
+__global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int M, int E,
+                                                           float p, uint64_t seed, float* __restrict__ y,
+                                                           float* __restrict__ s_out, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nv = E / 4;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * E);
+    const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (int64_t)row * E) : nullptr;
+    const float inv_keep = 1.0f / (1.0f - p);
+    f32x4 v[LN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+        const int c = lane + 64 * u;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            v[u] = xr[c];
+            if (p > 0.f) {
+                const uint64_t e0 = (uint64_t)row * E + 4 * c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[u][k] *= drop_scale(seed, e0 + k, p, inv_keep);
+            }
+            if (ar) v[u] += ar[c];
+            sum += v[u][0] + v[u][1] + v[u][2] + v[u][3];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)E;
+    if (s_out) {
+        f32x4* sr = reinterpret_cast<f32x4*>(s_out + (int64_t)row * E);
+#pragma unroll
+        for (int u = 0; u < LN_MAXV; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nv) sr[c] = v[u];
+        }
+    }
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nv) {
+            v[u] -= mean;
+            q += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
+    f32x4* yr = reinterpret_cast<f32x4*>(y + (int64_t)row * E);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nv) yr[c] = v[u] * rstd * g4[c] + b4[c];
+    }
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+// ---- LayerNorm backward -----------------------------------------------------------------------------
+// ds = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma, xhat = (s - mean) * rstd
+// d_add = ds ; d_x = ds * dropout mask ; dgamma += sum_r dy * xhat ; dbeta += sum_r dy
+constexpr int LNB_ROWS = 32;   // rows per workgroup (8 per wavefront)
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, int M, int E, float p,
+                                                     uint64_t seed, float* __restrict__ d_add, float* __restrict__ d_x,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][2][E]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nv = E / 4;
+    const float inv_keep = 1.0f / (1.0f - p);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+    f32x4 gam[LN_MAXV], ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+        const int c = lane + 64 * u;
+        gam[u] = c < nv ? g4[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        ag[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ab[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int r0 = blockIdx.x * LNB_ROWS;
+    for (int rr = wave; rr < LNB_ROWS; rr += 4) {
+        const int row = r0 + rr;
+        if (row >= M) break;
+        const f32x4* dyr = reinterpret_cast<const f32x4*>(dy + (int64_t)row * E);
+        const f32x4* sr = reinterpret_cast<const f32x4*>(s + (int64_t)row * E);
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 g[LN_MAXV], xh[LN_MAXV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < LN_MAXV; ++u) {
+            const int c = lane + 64 * u;
+            g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xh[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < nv) {
+                const f32x4 d = dyr[c];
+                xh[u] = (sr[c] - mu) * rs;
+                ag[u] += d * xh[u];
+                ab[u] += d;
+                g[u] = d * gam[u];
+                c1 += g[u][0] + g[u][1] + g[u][2] + g[u][3];
+                c2 += g[u][0] * xh[u][0] + g[u][1] * xh[u][1] + g[u][2] * xh[u][2] + g[u][3] * xh[u][3];
+            }
+        }
+        c1 = wave_sum(c1) / (float)E;
+        c2 = wave_sum(c2) / (float)E;
+#pragma unroll
+        for (int u = 0; u < LN_MAXV; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nv) {
+                f32x4 ds = (g[u] - c1 - xh[u] * c2) * rs;
+                if (d_add) reinterpret_cast<f32x4*>(d_add + (int64_t)row * E)[c] = ds;
+                if (d_x) {
+                    if (p > 0.f) {
+                        const uint64_t e0 = (uint64_t)row * E + 4 * c;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) ds[k] *= drop_scale(seed, e0 + k, p, inv_keep);
+                    }
+                    reinterpret_cast<f32x4*>(d_x + (int64_t)row * E)[c] = ds;
+                }
+            }
+        }
+    }
+    // combine the 4 wavefronts' column partials, then one atomic per column and workgroup
+    float* pg = lds + (wave * 2 + 0) * E;
+    float* pb = lds + (wave * 2 + 1) * E;
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nv) {
+            reinterpret_cast<f32x4*>(pg)[c] = ag[u];
+            reinterpret_cast<f32x4*>(pb)[c] = ab[u];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < E; c += 256) {
+        float sg = 0.f, sb = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            sg += lds[(w * 2 + 0) * E + c];
+            sb += lds[(w * 2 + 1) * E + c];
+        }
+        atomicAdd(&dgamma[c], sg);
+        atomicAdd(&dbeta[c], sb);
+    }
+}
+
+// ---- column sums: out[j] += sum_i x[i*ldx + j]  (bias gradients) -------------------------------------
+constexpr int CS_ROWS = 256;
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
+                                                     float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * CS_ROWS;
+    const int r1 = min(M, r0 + CS_ROWS);
+    float s = 0.f;
+    if (j < N)
+        for (int r = r0 + wave; r < r1; r += 4) s += x[(int64_t)r * ldx + j];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < N) atomicAdd(&out[j], red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+// ---- embedding backward: demb[ids[r], :] += dx[r, :] ----------------------------------------------
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
+                                                        int rows, int E, int V, float* __restrict__ demb) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const float* src = dx + (int64_t)row * E;
+    float* dst = demb + id * (int64_t)E;
+    for (int c = lane; c < E; c += 64) atomicAdd(&dst[c], src[c]);
+}
+
+// ---- BatchNorm1d backward (training statistics) ------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, int B, int C,
+                                                     float* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < C;
+    const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok)
+        for (int r = wave; r < B; r += 4) {
+            const float d = dy[(int64_t)r * C + c];
+            s1 += d;
+            s2 += d * (x[(int64_t)r * C + c] - mu) * rs;
+        }
+    red[0][wave][lane] = s1;
+    red[1][wave][lane] = s2;
+    __syncthreads();
+    s1 = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    s2 = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    if (!ok) return;
+    const float g = gamma[c];
+    const float k = g * rs;
+    for (int r = wave; r < B; r += 4) {
+        const float xh = (x[(int64_t)r * C + c] - mu) * rs;
+        dx[(int64_t)r * C + c] = k * (dy[(int64_t)r * C + c] - s1 / (float)B - xh * s2 / (float)B);
+    }
+    if (wave == 0) {
+        dgamma[c] += s2;
+        dbeta[c] += s1;
+    }
+}
+
+// ---- attention backward --------------------------------------------------------------------------------
+struct AttnBwdArgs {
+    const float* q; int64_t ldq;
+    const float* k; int64_t ldk, sk;
+    const float* v; int64_t ldv, sv;
+    const float* dout; int64_t ldo;
+    const float* lse;            // [B,H,Tq]
+    float* dsum;                 // [B,H,Tq]  D_i = sum_j p_ij dp_ij (written by the query pass)
+    float* dq; int64_t lddq;
+    float* dk; int64_t lddk, sdk;
+    float* dv; int64_t lddv, sdv;
+    int B, H, Tq, Tk, dk_;
+    int causal, causal_off;
+    const int32_t* ids; int64_t ldid;
+};
+
+__device__ __forceinline__ float dot_parts(const f32x4 (&a)[16], const float* __restrict__ p, int nm) {
+    float d = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        if (m < nm) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p + 16 * m);
+            d += a[m][0] * b[0] + a[m][1] * b[1] + a[m][2] * b[2] + a[m][3] * b[3];
+        }
+    return d;
+}
+__device__ __forceinline__ void load_parts(f32x4 (&a)[16], const float* __restrict__ p, int nm) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a[m] = (m < nm) ? *reinterpret_cast<const f32x4*>(p + 16 * m) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ float quad_sum(float d) {
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    return d;
+}
+__device__ __forceinline__ void group_reduce(f32x4& acc, int lpv) {
+    for (int o = lpv; o < 64; o <<= 1) {
+        acc[0] += __shfl_xor(acc[0], o, 64);
+        acc[1] += __shfl_xor(acc[1], o, 64);
+        acc[2] += __shfl_xor(acc[2], o, 64);
+        acc[3] += __shfl_xor(acc[3], o, 64);
+    }
+}
+
+// query pass: one wavefront per (b,h,i): D_i and dq_i
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long total = (long)a.B * a.H * a.Tq;
+    long idx = (long)blockIdx.x * 4 + wave;
+    const bool live = idx < total;
+    if (!live) idx = total - 1;
+    const int i = (int)(idx % a.Tq), h = (int)((idx / a.Tq) % a.H), b = (int)(idx / ((long)a.Tq * a.H));
+    float* ps = lds + wave * 2 * a.Tk;      // p_ij
+    float* dps = ps + a.Tk;                 // dp_ij = dO_i . v_j
+    const int dk = a.dk_;
+    const bool pad_row = a.ids && a.ids[(int64_t)b * a.ldid + i] == 0;
+    int nkeys = a.Tk;
+    if (a.causal && !pad_row) {
+        nkeys = i + a.causal_off + 1;
+        nkeys = nkeys < 1 ? 1 : (nkeys > a.Tk ? a.Tk : nkeys);
+    }
+    const float scale = sqrtf((float)dk);
+    const int64_t qoff = ((int64_t)b * a.Tq + i);
+    const float* kb = a.k + (int64_t)b * a.sk + (int64_t)h * dk;
+    const float* vb = a.v + (int64_t)b * a.sv + (int64_t)h * dk;
+    float D = 0.f;
+    if (!pad_row) {
+        // 4 lanes per key, 16 keys per sweep step; q_i and dO_i stay in registers
+        const int part = lane & 3, kl = lane >> 2, nm = dk / 16;
+        f32x4 qreg[16], oreg[16];
+        load_parts(qreg, a.q + qoff * a.ldq + (int64_t)h * dk + 4 * part, nm);
+        load_parts(oreg, a.dout + qoff * a.ldo + (int64_t)h * dk + 4 * part, nm);
+        const float l = a.lse[idx];
+        float dacc = 0.f;
+        for (int j0 = 0; j0 < nkeys; j0 += 16) {
+            const int j = j0 + kl;
+            float s = 0.f, dp = 0.f;
+            if (j < nkeys) {
+                s = dot_parts(qreg, kb + (int64_t)j * a.ldk + 4 * part, nm);
+                dp = dot_parts(oreg, vb + (int64_t)j * a.ldv + 4 * part, nm);
+            }
+            s = quad_sum(s);
+            dp = quad_sum(dp);
+            if (j < nkeys && part == 0) {
+                const float p = expf(s / scale - l);
+                ps[j] = p;
+                dps[j] = dp;
+                dacc += p * dp;
+            }
+        }
+        D = wave_sum(dacc);
+    }
+    __syncthreads();
+    // dq_i = sum_j p_ij (dp_ij - D_i) k_j / sqrt(dk); a PAD row's softmax is constant, so its dq is zero
+    const int lpv = dk / 4, grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (!pad_row)
+        for (int j = grp; j < nkeys; j += ngrp)
+            acc += *reinterpret_cast<const f32x4*>(kb + (int64_t)j * a.ldk + 4 * dl) * (ps[j] * (dps[j] - D) / scale);
+    group_reduce(acc, lpv);
+    if (live && grp == 0) *reinterpret_cast<f32x4*>(a.dq + qoff * a.lddq + (int64_t)h * dk + 4 * dl) = acc;
+    if (live && lane == 0) a.dsum[idx] = D;
+}
+
+// key pass: one wavefront per (b,h,j): dk_j and dv_j
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long total = (long)a.B * a.H * a.Tk;
+    long idx = (long)blockIdx.x * 4 + wave;
+    const bool live = idx < total;
+    if (!live) idx = total - 1;
+    const int j = (int)(idx % a.Tk), h = (int)((idx / a.Tk) % a.H), b = (int)(idx / ((long)a.Tk * a.H));
+    float* pp = lds + wave * 2 * a.Tq;     // p_ij for i in [0,Tq)
+    float* dd = pp + a.Tq;                 // ds_ij
+    const int dk = a.dk_;
+    const float scale = sqrtf((float)dk);
+    const int part = lane & 3, il = lane >> 2, nm = dk / 16;
+    const float* kj = a.k + (int64_t)b * a.sk + (int64_t)j * a.ldk + (int64_t)h * dk;
+    const float* vj = a.v + (int64_t)b * a.sv + (int64_t)j * a.ldv + (int64_t)h * dk;
+    f32x4 kreg[16], vreg[16];
+    load_parts(kreg, kj + 4 * part, nm);
+    load_parts(vreg, vj + 4 * part, nm);
+    for (int i0 = 0; i0 < a.Tq; i0 += 16) {
+        const int i = i0 + il;
+        float s = 0.f, dp = 0.f;
+        bool pad_row = false, seen = false;
+        if (i < a.Tq) {
+            pad_row = a.ids && a.ids[(int64_t)b * a.ldid + i] == 0;
+            seen = pad_row || !a.causal || (j <= i + a.causal_off);
+            if (seen && !pad_row) {
+                const int64_t qoff = (int64_t)b * a.Tq + i;
+                s = dot_parts(kreg, a.q + qoff * a.ldq + (int64_t)h * dk + 4 * part, nm);
+                dp = dot_parts(vreg, a.dout + qoff * a.ldo + (int64_t)h * dk + 4 * part, nm);
+            }
+        }
+        s = quad_sum(s);
+        dp = quad_sum(dp);
+        if (i < a.Tq && part == 0) {
+            float p = 0.f, d = 0.f;
+            if (pad_row) {
+                p = 1.0f / (float)a.Tk;            // uniform row: no dependence on q or k
+            } else if (seen) {
+                const long ri = ((long)b * a.H + h) * a.Tq + i;
+                p = expf(s / scale - a.lse[ri]);
+                d = p * (dp - a.dsum[ri]);
+            }
+            pp[i] = p;
+            dd[i] = d;
+        }
+    }
+    __syncthreads();
+    const int lpv = dk / 4, grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
+    f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+    for (int i = grp; i < a.Tq; i += ngrp) {
+        const int64_t qoff = (int64_t)b * a.Tq + i;
+        const float p = pp[i], d = dd[i];
+        if (p != 0.f) av += *reinterpret_cast<const f32x4*>(a.dout + qoff * a.ldo + (int64_t)h * dk + 4 * dl) * p;
+        if (d != 0.f) ak += *reinterpret_cast<const f32x4*>(a.q + qoff * a.ldq + (int64_t)h * dk + 4 * dl) * (d / scale);
+    }
+    group_reduce(ak, lpv);
+    group_reduce(av, lpv);
+    if (live && grp == 0) {
+        *reinterpret_cast<f32x4*>(a.dk + (int64_t)b * a.sdk + (int64_t)j * a.lddk + (int64_t)h * dk + 4 * dl) = ak;
+        *reinterpret_cast<f32x4*>(a.dv + (int64_t)b * a.sdv + (int64_t)j * a.lddv + (int64_t)h * dk + 4 * dl) = av;
+    }
+}
+
+// ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) over one flat buffer -----------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+// loss = sum nll / n valid ; gscale = 1 / n valid  (CrossEntropyLoss(ignore_index) mean reduction)
+__global__ void loss_finish_kernel(const float* __restrict__ sums, float* __restrict__ loss, float* __restrict__ gscale) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        loss[0] = sums[0] / sums[1];
+        gscale[0] = 1.0f / sums[1];
+    }
+}
+
+inline int grid_for(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, void* stream) {
+    CAPDEC_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, p, seed, y);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_add_layernorm_train(const float* x, const float* add, const float* gamma, const float* beta, float eps,
+                               int M, int E, float p, uint64_t seed, float* y, float* s_out, float* mean, float* rstd,
+                               void* stream) {
+    CAPDEC_REQUIRE(x && gamma && beta && y && M >= 0 && E >= 4 && E % 4 == 0 && E <= 256 * LN_MAXV && p >= 0.f && p < 1.f);
+    if (!capdec_aligned16(x) || !capdec_aligned16(y) || !capdec_aligned16(gamma) || !capdec_aligned16(beta) ||
+        (add && !capdec_aligned16(add)) || (s_out && !capdec_aligned16(s_out)))
+        return CAPDEC_EALIGN;
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(ln_train_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
+                       eps, M, E, p, seed, y, s_out, mean, rstd);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
+                         int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma, float* dbeta,
+                         void* stream) {
+    CAPDEC_REQUIRE(dy && s && mean && rstd && gamma && dgamma && dbeta && M >= 0 && E >= 4 && E % 4 == 0 &&
+                   E <= 256 * LN_MAXV && p >= 0.f && p < 1.f);
+    if (!capdec_aligned16(dy) || !capdec_aligned16(s) || !capdec_aligned16(gamma) || (d_add && !capdec_aligned16(d_add)) ||
+        (d_x && !capdec_aligned16(d_x)))
+        return CAPDEC_EALIGN;
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 8 * E * sizeof(float),
+                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, d_add, d_x, dgamma, dbeta);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream) {
+    CAPDEC_REQUIRE(x && out && M >= 0 && N >= 1 && ldx >= N);
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, M, N, out);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_embed_bwd(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb, void* stream) {
+    CAPDEC_REQUIRE(ids && dx && demb && rows >= 0 && E >= 1 && V >= 1);
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, dx, rows, E, V,
+                       demb);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma, const float* save_mean,
+                             const float* save_rstd, int B, int C, float* dx, float* dgamma, float* dbeta,
+                             void* stream) {
+    CAPDEC_REQUIRE(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && B >= 1 && C >= 1);
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, save_mean,
+                       save_rstd, B, C, dx, dgamma, dbeta);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
+                         int64_t ldv, int64_t sv, const float* dout, int64_t ldo, const float* lse, float* dsum,
+                         float* dq, int64_t lddq, float* dk, int64_t lddk, int64_t sdk, float* dv, int64_t lddv,
+                         int64_t sdv, int B, int H, int Tq, int Tk, int dkh, int causal, int causal_off,
+                         const int32_t* ids, int64_t ldid, void* stream) {
+    CAPDEC_REQUIRE(q && k && v && dout && lse && dsum && dq && dk && dv && B >= 0 && H >= 1 && Tq >= 1 && Tk >= 1 &&
+                   Tk <= 2048 && Tq <= 2048);
+    CAPDEC_REQUIRE(dkh == 16 || dkh == 32 || dkh == 64 || dkh == 128 || dkh == 256);
+    CAPDEC_REQUIRE(!ids || ldid >= Tq);
+    if (!capdec_aligned16(q) || !capdec_aligned16(k) || !capdec_aligned16(v) || !capdec_aligned16(dout) ||
+        !capdec_aligned16(dq) || !capdec_aligned16(dk) || !capdec_aligned16(dv) || ldq % 4 || ldk % 4 || sk % 4 ||
+        ldv % 4 || sv % 4 || ldo % 4 || lddq % 4 || lddk % 4 || sdk % 4 || lddv % 4 || sdv % 4)
+        return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    AttnBwdArgs a{q, ldq, k, ldk, sk, v, ldv, sv, dout, ldo, lse, dsum, dq, lddq, dk, lddk, sdk, dv, lddv, sdv,
+                  B, H, Tq, Tk, dkh, causal, causal_off, ids, ldid};
+    hipStream_t s = (hipStream_t)stream;
+    const long tq = (long)B * H * Tq, tk = (long)B * H * Tk;
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((tq + 3) / 4)), dim3(256), 4 * 2 * Tk * sizeof(float), s, a);
+    CAPDEC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((tk + 3) / 4)), dim3(256), 4 * 2 * Tq * sizeof(float), s, a);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_loss_finish(const float* sums, float* loss, float* gscale, void* stream) {
+    CAPDEC_REQUIRE(sums && loss && gscale);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, loss, gscale);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, int step, float grad_scale, void* stream) {
+    CAPDEC_REQUIRE(p && g && m && v && n >= 0 && step >= 1);
+    if (n == 0) return 0;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                       beta2, eps, bc1, bc2_sqrt, grad_scale);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

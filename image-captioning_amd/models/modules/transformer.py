@@ -103,7 +103,7 @@ class DecoderTransformer(ABC, nn.Module):
         whole stack."""
         needs_graph = torch.is_grad_enabled() and (
             enc_output.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_graph:
+        if needs_graph or (self.training and self.dropout.p > 0 and not take_last):
             return CF.decoder_forward(self, enc_output, captions, take_last)
         return engine.tf_forward_logits(self, enc_output, captions, take_last)
 

@@ -57,7 +57,25 @@ typedef struct capdec_gemm_group {
 } capdec_gemm_group;
 
 #define CAPDEC_GEMM_RELU 1
+#define CAPDEC_GEMM_TP 2     /* P is stored [K, I] (element (i,k) at P[k*ldp + i]); needs TQ as well   */
+#define CAPDEC_GEMM_TQ 4     /* Q is stored [K, J] (element (j,k) at Q[k*ldq + j])                      */
 int capdec_gemm(const capdec_gemm_group* groups /*host*/, int ngroups, int K, int flags, void* stream);
+
+/* Backward forms of nn.Linear y = x W^T + b (autograd of the same reference lines) use the layout flags:
+ *   dX[m,k] = sum_n dY[m,n] W[n,k] :  P = dY [M,N], Q = W stored [N(k-axis), K(j-axis)]  -> TQ
+ *   dW[n,k] = sum_m dY[m,n] X[m,k] :  P = dY stored [M(k-axis), N], Q = X stored [M, K]   -> TP | TQ
+ * and two extra epilogues (applied after bias/scale/relu, before the residual R, which doubles as
+ * "accumulate into C" when R == C):
+ *   mask  : v = 0 where mask[i*ldm + j] <= 0        (ReLU backward with the saved activation)
+ *   lse   : v = (exp(v - lse[i]) - (tgt[i] == j)) * gscale[0], or 0 where tgt[i] == ignore_index
+ *           (gradient of CrossEntropyLoss(ignore_index) w.r.t. the logits, recomputed from the projection;
+ *            gscale is a device scalar, normally 1 / number of counted targets; train.py:216,254-256) */
+typedef struct capdec_gemm_extra {
+    const float* mask; int64_t ldm;
+    const float* lse; const int64_t* tgt; const float* gscale; int64_t ignore_index;
+} capdec_gemm_extra;
+int capdec_gemm_ex(const capdec_gemm_group* groups /*host*/, int ngroups, int K, int flags,
+                   const capdec_gemm_extra* extra /*host, nullable*/, void* stream);
 
 /* Vocabulary projection fused with row arg-max (logits are never written):
  *   replaces fc2 + argmax, transformer.py:137,155 and cnnrnn_model.py:84-90 (log_softmax is
@@ -120,6 +138,45 @@ int capdec_bn_fold(const float* gamma, const float* beta, const float* running_m
 int capdec_bn_train_forward(const float* x, const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, int B, int C, float* y, float* save_mean,
                             float* save_rstd, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training-side kernels: autograd of the same reference lines (train.py:252-262 drives them through
+ * loss.backward(); dropout is nn.Dropout at transformer.py:85,87,89,126 and in the wrappers).
+ * Dropout masks come from a counter-based generator keyed by (seed, element index): the backward pass
+ * regenerates the mask from the same seed, nothing is stored.  Column-reduced gradients (dgamma, dbeta,
+ * bias and embedding gradients) are ACCUMULATED into their outputs with float atomics: zero them first.
+ * ------------------------------------------------------------------------------------------ */
+int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, void* stream);
+/* s = add + dropout_p(x) ; y = LayerNorm(s) ; s_out/mean/rstd (nullable) are saved for the backward pass */
+int capdec_add_layernorm_train(const float* x, const float* add, const float* gamma, const float* beta, float eps,
+                               int M, int E, float p, uint64_t seed, float* y, float* s_out, float* mean, float* rstd,
+                               void* stream);
+/* d_add = dLN/ds ; d_x = d_add * dropout mask (same p, seed as the forward) ; dgamma/dbeta accumulated */
+int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
+                         int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma, float* dbeta,
+                         void* stream);
+/* out[j] += sum_i x[i*ldx + j] */
+int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream);
+/* demb[ids[r],:] += dx[r,:]  (nn.Embedding backward, transformer.py:126 / cnnrnn_model.py:27) */
+int capdec_embed_bwd(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb, void* stream);
+int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma, const float* save_mean,
+                             const float* save_rstd, int B, int C, float* dx, float* dgamma, float* dbeta,
+                             void* stream);
+/* Backward of capdec_attention (same layout and mask arguments): lse from the forward; dsum is scratch
+ * [B,H,Tq]; dq/dk/dv are written (not accumulated).  A PAD query row has a constant uniform softmax: it
+ * contributes to dv only. */
+int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
+                         int64_t ldv, int64_t sv, const float* dout, int64_t ldo, const float* lse, float* dsum,
+                         float* dq, int64_t lddq, float* dk, int64_t lddk, int64_t sdk, float* dv, int64_t lddv,
+                         int64_t sdv, int B, int H, int Tq, int Tk, int dkh, int causal, int causal_off,
+                         const int32_t* ids, int64_t ldid, void* stream);
+/* sums = (sum of nll, number of counted targets) from capdec_nll_finalize:
+ * loss[0] = sums[0] / sums[1] (nn.CrossEntropyLoss mean over non-ignored targets), gscale[0] = 1 / sums[1] */
+int capdec_loss_finish(const float* sums, float* loss, float* gscale, void* stream);
+/* torch.optim.Adam defaults (train.py:217): p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) over one flat
+ * buffer; g is multiplied by grad_scale first (1/world for a summed all-reduce). */
+int capdec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, int step, float grad_scale, void* stream);
 
 /* One LSTM step, gate order i,f,g,o (nn.LSTM, cnnrnn_model.py:17,29-30,83):
  *   gates = x W_ih^T + b_ih + h W_hh^T + b_hh ; c' = s(f) c + s(i) tanh(g) ; h' = s(o) tanh(c')

@@ -1,0 +1,171 @@
+"""GPU parity of the training path: teacher-forced forward, loss and every gradient against the golden
+vectors produced by the reference (autograd on its own classes).  Tolerance: 1e-4 relative (per tensor,
+relative to the tensor's max magnitude), dropout disabled (dropout parity is statistical only)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub_sd
+from gpu_util import REL, close, decoder_from_sd
+
+pytestmark = pytest.mark.gpu
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def _noise_floor(fx, key_fmt, names):
+    """Some gradients are mathematically zero (e.g. the key bias: softmax is invariant to a constant added to
+    every score of a row) and hold only rounding noise (~1e-10) in the reference too; compare those against
+    1e-6 of the largest gradient magnitude in the model instead of against their own magnitude."""
+    big = max(float(np.abs(fx[key_fmt.format(n)]).max()) for n in names if key_fmt.format(n) in fx)
+    return 1e-6 * big
+
+
+def _check_grads(named_params, fx, key_fmt, rtol=REL):
+    named_params = list(named_params)
+    atol = _noise_floor(fx, key_fmt, [n for n, _ in named_params])
+    n = 0
+    for name, prm in named_params:
+        key = key_fmt.format(name)
+        if key not in fx:
+            continue
+        g = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+        close(g, fx[key], rtol=rtol, atol=atol, what=name)
+        n += 1
+    return n
+
+
+@pytest.mark.parametrize("S", [1, 2, 5])
+def test_f4_logits_loss_and_all_gradients_via_autograd(S):
+    fx = load_golden("f4_decoder_forward")
+    dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
+    caps = t(fx["captions"]).cuda()
+    enc = t(fx[f"enc_S{S}"]).cuda().requires_grad_(True)
+    logits = dec.decoder_forward(enc, caps[:, :-1])
+    close(logits, fx[f"logits_S{S}"], what="logits")
+    V = logits.shape[-1]
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, V), caps[:, 1:].reshape(-1), ignore_index=0)
+    close(loss, fx[f"loss_S{S}"], rtol=1e-5, what="loss")
+    loss.backward()
+    close(enc.grad, fx[f"denc_S{S}"], what="denc")
+    n = _check_grads(dec.named_parameters(), fx, "grad__{}@S" + str(S))
+    assert n == len(list(dec.parameters()))
+    if S == 1:   # softmax over one memory row is constant: exactly zero gradient for the cross W_q / W_k
+        for l in range(2):
+            assert float(dec.decoder_layers[l].cross_attn.W_q.weight.grad.abs().max()) == 0.0
+            assert float(dec.decoder_layers[l].cross_attn.W_k.weight.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("S", [1, 5])
+def test_f4_fused_loss_path(S):
+    """Projection + log-sum-exp + NLL without logits, and its backward, against the same golden vectors."""
+    from capdec import autograd as AG
+    fx = load_golden("f4_decoder_forward")
+    dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
+    caps = t(fx["captions"]).cuda()
+    enc = t(fx[f"enc_S{S}"]).cuda()
+    x, tape = AG.tf_forward(dec, enc, caps[:, :-1].contiguous(), 0.0, 0)
+    loss, saved = AG.vocab_loss(dec, x, caps[:, 1:].contiguous())
+    close(loss[0], fx[f"loss_S{S}"], rtol=1e-5, what="loss")
+    grads = {}
+    dx = AG.vocab_loss_bwd(dec, x, saved, grads)
+    denc = AG.tf_backward(dec, tape, dx, grads)
+    close(denc, fx[f"denc_S{S}"], what="denc")
+    names = [n for n, _ in dec.named_parameters()]
+    atol = _noise_floor(fx, "grad__{}@S" + str(S), names)
+    for name in names:
+        close(grads[name], fx[f"grad__{name}@S{S}"], atol=atol, what=name)
+
+
+def test_f6_cnn_attn_train_mode_batchnorm_and_head_gradients():
+    from models.cnnattn_model import CNNAttentionModel
+    fx = load_golden("f6_heads")
+    m = CNNAttentionModel(64, 50, int(fx["H"]), 2, dropout=0.0)
+    m.load_state_dict(sub_sd(fx, "cnn__sd__"))
+    m = m.cuda().train()
+    feats, caps = t(fx["cnn_feats"]).cuda(), t(fx["captions"]).cuda()
+    logits = m(feats, caps[:, :-1])
+    close(logits, fx["cnn_logits_train"], what="logits")
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, 50), caps[:, 1:].reshape(-1), ignore_index=0)
+    close(loss, fx["cnn_loss_train"], rtol=1e-5)
+    loss.backward()
+    n = _check_grads(m.named_parameters(), fx, "cnn_grad__{}", rtol=2e-4)
+    assert n == len(list(m.parameters()))
+    for k in ("running_mean", "running_var", "num_batches_tracked"):
+        close(getattr(m.batchnorm, k).float(), fx["cnn_after__batchnorm." + k].astype(np.float32), rtol=1e-5, what=k)
+
+
+def test_f6_pair_head_train_mode():
+    from models.vitcnnattn_model import VITCNNAttentionModel
+    fx = load_golden("f6_heads")
+    sd = sub_sd(fx, "pair__sd__")
+    split = int(fx["pair_split"])
+    m = VITCNNAttentionModel(64, 50, int(fx["H"]), 1, dropout=0.0)
+    m.vit_out_size = split
+    m.fc_vit = torch.nn.Linear(split, 64)
+    m.fc_cnn = torch.nn.Linear(sd["fc_cnn.weight"].shape[1], 64)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    feats, caps = t(fx["pair_feats"]).cuda(), t(fx["captions"]).cuda()
+    logits = m(feats, caps[:, :-1], "precomputed")
+    close(logits, fx["pair_logits_train"], what="logits")
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, 50), caps[:, 1:].reshape(-1), ignore_index=0)
+    close(loss, fx["pair_loss_train"], rtol=1e-5)
+    loss.backward()
+    n = _check_grads(m.named_parameters(), fx, "pair_grad__{}", rtol=2e-4)
+    assert n == len(list(m.parameters()))
+
+
+def test_dropout_statistics_and_mask_replay():
+    from capdec import ops
+    x = torch.ones(1 << 20, device="cuda")
+    y = ops.dropout(x, 0.1, 12345)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.9) < 2e-3
+    assert torch.all((y == 0) | ((y - 1 / 0.9).abs() < 1e-6))
+    assert torch.equal(y, ops.dropout(x, 0.1, 12345))            # same seed -> same mask (backward replays it)
+    assert not torch.equal(y, ops.dropout(x, 0.1, 12346))
+    # LayerNorm with fused dropout: s = add + drop(x) uses the same generator
+    g, b = torch.ones(512, device="cuda"), torch.zeros(512, device="cuda")
+    xx = torch.randn(64, 512, device="cuda")
+    add = torch.randn(64, 512, device="cuda")
+    _, s, _, _ = ops.add_layernorm_train(xx, add, g, b, 0.1, 777)
+    close(s, add + ops.dropout(xx, 0.1, 777), rtol=1e-6)
+    dy = torch.randn(64, 512, device="cuda")
+    dg, db = torch.zeros(512, device="cuda"), torch.zeros(512, device="cuda")
+    _, _, mean, rstd = ops.add_layernorm_train(xx, add, g, b, 0.1, 777)
+    d_add, d_x = ops.layernorm_bwd(dy, s, mean, rstd, g, 0.1, 777, dg, db)
+    close(d_x, ops.dropout(d_add, 0.1, 777), rtol=1e-6)
+
+
+def test_train_mode_with_dropout_runs_and_is_seeded():
+    fx = load_golden("f4_decoder_forward")
+    dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"]), dropout=0.1).train()
+    caps = t(fx["captions"]).cuda()
+    enc = t(fx["enc_S2"]).cuda()
+    torch.manual_seed(3)
+    a = dec.decoder_forward(enc, caps[:, :-1])
+    torch.manual_seed(3)
+    b = dec.decoder_forward(enc, caps[:, :-1])
+    c = dec.decoder_forward(enc, caps[:, :-1])
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    a.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in dec.parameters())
+
+
+def test_adam_step_matches_torch_formula():
+    from capdec import ops
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(10000, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.clone().cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        grad = torch.randn(10000, generator=g)
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adam_step(p, grad.cuda(), m, v, 1e-3, step)
+    close(p, ref.detach(), rtol=1e-6)
