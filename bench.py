@@ -62,6 +62,52 @@ def cpu_baseline(target_seconds=12.0):
                       f"{dt:.1f} s on {threads} torch CPU threads"}
 
 
+def train_bench(device, rank, world, steps, warmup, fence):
+    """BASELINE.json configs[2]: ViT-Attn teacher-forced training, B=512 per GPU (the reference's DDP draws a full
+    batch per rank), T=20, E=512, H=4, L=3, V=10000, features [512,1000] -> one memory row (reference-faithful).
+    One step = head + decoder forward, fused CE loss, backward, RCCL gradient all-reduce, Adam."""
+    from capdec.trainer import CaptionTrainer
+    from models.vitattn_model import VITAttentionModel
+    Bt, T, Lt = 512, 20, 3
+    torch.manual_seed(0)
+    model = VITAttentionModel(E, V, H, Lt).to(device)
+    tr = CaptionTrainer(model, lr=1e-3)
+    g = torch.Generator().manual_seed(1234 + 3 + 1000 * rank)
+    feats = torch.rand(Bt, 1000, generator=g).to(device)
+    caps = torch.zeros(Bt, T + 1, dtype=torch.long)
+    for b in range(Bt):
+        n = int(torch.randint(8, 20, (1,), generator=g))       # caption body length in [8,19]
+        caps[b, 0] = 1
+        caps[b, 1:1 + n] = torch.randint(4, V, (n,), generator=g)
+        caps[b, 1 + n] = 2
+    caps = caps.to(device)
+    first = None
+    for _ in range(warmup):
+        loss = tr.step(feats, caps)
+        first = first if first is not None else float(loss.item())
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(feats, caps)
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    # algorithmic FLOPs per sample (2 per MAC): forward = L*(16TE^2 + 4SE^2 + 4T^2E + 4TSE) + 2TEV + 2DE; x3 for training
+    S = 1
+    f_fwd = Lt * (16 * T * E * E + 4 * S * E * E + 4 * T * T * E + 4 * T * S * E) + 2 * T * E * V + 2 * 1000 * E
+    tflops = 3.0 * f_fwd * world * Bt * steps / dt / 1e12
+    return {"metric": "teacher-forced train samples/sec", "value": world * Bt * steps / dt, "unit": "samples/s",
+            "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "scaling": "weak",
+            "config": {"workload": f"cfg3 ViT-Attn training, B={Bt}/GPU, T={T}, E={E}, H={H}, L={Lt}, V={V}, "
+                                   "memory rows S=1, dropout 0.1, Adam lr 1e-3", "global_batch": world * Bt,
+                       "grad_allreduce_bytes": tr.grad_bytes()},
+            "algorithmic_tflops": tflops, "mfma_frac": tflops / (world * FP32_MFMA_PEAK_TFLOPS),
+            "loss_first": first, "loss_last": float(loss.item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=1, help="memory rows S (1 = reference-faithful pooled feature)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed training steps of cfg3 (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,6 +180,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    train = None
+    if args.train_steps > 0:
+        del model
+        train = train_bench(device, rank, world, args.train_steps, 3, fence)
+
     if rank == 0:
         captions = world * B * args.steps
         avg_ms = sum(vocab_ms) / len(vocab_ms)
@@ -151,6 +203,8 @@ def main():
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "avg_launch_ms": avg_ms,
                          "launches_timed": len(vocab_ms), "traffic": None},
         }
+        if train is not None:
+            out["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

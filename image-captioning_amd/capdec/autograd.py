@@ -91,7 +91,7 @@ def tf_forward(dec, enc, ids, p, seed):
     return x, t
 
 
-def tf_backward(dec, t, dx, grads, need_denc=True):
+def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
     """Backward of ``tf_forward``.  dx [B*T,E].  Fills ``grads`` (keys = names under ``dec``); returns denc
     [B,S,E] (or None)."""
     B, S, T, E, H, p = t.B, t.S, t.T, t.E, t.H, t.p
@@ -127,6 +127,8 @@ def tf_backward(dec, t, dx, grads, need_denc=True):
         _lin_bwd(grads, pre + "self_attn.W_k", sa.W_k, dk, c.x, accum=d_x)
         _lin_bwd(grads, pre + "self_attn.W_v", sa.W_v, dv, c.x, accum=d_x)
         dx = d_x
+        if on_layer_done is not None:
+            on_layer_done(l)          # every gradient of layer l is now enqueued
     if p > 0:
         dx = ops.dropout(dx, p, t.seed)
     ops.embed_bwd(t.ids.view(-1), dx, _new(grads, "decoder_embedding.weight", dec.decoder_embedding.weight))

@@ -1,0 +1,126 @@
+"""Teacher-forced training step on the HIP kernels with one flat parameter / gradient buffer.
+
+Reproduces the reference's inner loop (train.py:252-262: forward, CrossEntropyLoss(ignore_index=<PAD>),
+backward, Adam) and its data-parallel hook (train.py:176,224-226,261: DDP averages the per-rank
+gradients; every rank's loss is the mean over its OWN non-PAD targets and its BatchNorm uses its OWN
+batch statistics).  Differences in mechanism, not in result:
+  * parameters are views of one flat fp32 buffer and gradients of another, laid out in the order the
+    backward pass completes them, so the gradient exchange is a handful of large RCCL all-reduces issued
+    while the rest of the backward pass is still running, and Adam is one kernel over the flat buffers;
+  * the [B*T, V] logits are never materialised in the forward pass (fused log-sum-exp + NLL).
+"""
+import torch
+import torch.distributed as dist
+
+from . import autograd as AG
+from . import dist as cdist
+from . import ops
+
+
+def _head_spec(model):
+    """(parts, names, dropout_first) of the model's feature head, mirroring models/modules/heads.py."""
+    if hasattr(model, "fc_yolo") and hasattr(model, "fc_cnn"):
+        return ("fc_yolo", model.yolo_output_size), "fc_cnn"
+    if hasattr(model, "fc_vit") and hasattr(model, "fc_cnn"):
+        return ("fc_vit", model.vit_out_size), "fc_cnn"
+    for n in ("fc1", "fc_vit", "fc_yolo"):
+        if hasattr(model, n):
+            return (n, None), None
+    raise RuntimeError("capdec: model has no feature head")
+
+
+class CaptionTrainer:
+    """One object per process (one process per GPU)."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, pad_idx=0):
+        self.model = model
+        self.lr, self.betas, self.eps, self.pad_idx = lr, betas, eps, pad_idx
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.t = 0
+        (self.fc_a, self.split), self.fc_b = _head_spec(model)
+        named = dict(model.named_parameters())
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("capdec: the trainer needs the model on the GPU (HIP); there is no CPU path")
+        # segments in the order the backward pass finishes them
+        L = len(model.decoder_layers)
+        seg_names = [[n for n in named if n.startswith("fc2.")]]
+        for l in range(L - 1, -1, -1):
+            seg_names.append([n for n in named if n.startswith(f"decoder_layers.{l}.")])
+        seg_names.append(["decoder_embedding.weight"])
+        seg_names.append([n for n in named if n.split(".")[0] in ("fc1", "fc_vit", "fc_cnn", "fc_yolo", "batchnorm")])
+        flat_names = [n for seg in seg_names for n in seg]
+        missing = set(named) - set(flat_names)
+        if missing:
+            raise RuntimeError(f"capdec: parameters outside the decoder hot path: {sorted(missing)}")
+        total = sum((named[n].numel() + 3) // 4 * 4 for n in flat_names)
+        self.flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grads, self.segments = {}, []
+        off = 0
+        with torch.no_grad():
+            for seg in seg_names:
+                start = off
+                for n in seg:
+                    prm = named[n]
+                    k = prm.numel()
+                    view = self.flat_p[off:off + k].view_as(prm)
+                    view.copy_(prm)
+                    prm.data = view                       # the module now reads and updates the flat buffer
+                    self.grads[n] = self.flat_g[off:off + k].view_as(prm)
+                    prm.grad = self.grads[n]
+                    off += (k + 3) // 4 * 4               # keep every tensor 16-byte aligned
+                self.segments.append((start, off))
+            self.flat_p[off:].zero_()
+        if self.world > 1:
+            cdist.broadcast_(self.flat_p, src=0, group=self.pg)   # DDP starts from rank 0's weights
+
+    # -----------------------------------------------------------------------------------------
+    def _reduce_segment(self, i, works):
+        if self.world > 1:
+            a, b = self.segments[i]
+            works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def step(self, feats, captions):
+        """feats: precomputed backbone features [B,D]; captions [B,T+1] int64 (inputs [:, :-1], targets [:, 1:]).
+        Returns the rank-local loss as a 1-element device tensor (no host sync)."""
+        model = self.model
+        model.train()
+        self.t += 1
+        self.flat_g.zero_()
+        ids = captions[:, :-1].contiguous()
+        tgt = captions[:, 1:].contiguous()
+        p = model.dropout.p
+        # ---- forward ----
+        parts = [(getattr(model, self.fc_a), 0, self.split if self.fc_b else feats.shape[1])]
+        names = [self.fc_a]
+        if self.fc_b:
+            parts.append((getattr(model, self.fc_b), self.split, feats.shape[1]))
+            names.append(self.fc_b)
+        y, htape = AG.head_forward(model, parts, feats, False, AG.draw_seed() if p > 0 else 0)
+        B = feats.shape[0]
+        enc = y.view(B, len(parts), -1)
+        x, tape = AG.tf_forward(model, enc, ids, p, AG.draw_seed() if p > 0 else 0)
+        loss, saved = AG.vocab_loss(model, x, tgt, self.pad_idx)
+        # ---- backward, gradient exchange overlapped segment by segment ----
+        works = []
+        dx = AG.vocab_loss_bwd(model, x, saved, self.grads)
+        self._reduce_segment(0, works)
+        denc = AG.tf_backward(model, tape, dx, self.grads, need_denc=True,
+                              on_layer_done=(lambda l: self._reduce_segment(len(model.decoder_layers) - l, works))
+                              if self.world > 1 else None)
+        self._reduce_segment(len(self.segments) - 2, works)          # embedding
+        AG.head_backward(model, names, htape, denc.reshape(B, -1), self.grads)
+        self._reduce_segment(len(self.segments) - 1, works)          # head
+        for w in works:
+            w.wait()
+        # ---- Adam over the flat buffers (DDP semantics: mean of the per-rank gradients) ----
+        ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1],
+                      self.eps, grad_scale=1.0 / self.world)
+        return loss
+
+    def grad_bytes(self):
+        return self.flat_g.numel() * 4

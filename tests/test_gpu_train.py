@@ -169,3 +169,61 @@ def test_adam_step_matches_torch_formula():
         opt.step()
         ops.adam_step(p, grad.cuda(), m, v, 1e-3, step)
     close(p, ref.detach(), rtol=1e-6)
+
+
+def test_trainer_steps_match_oracle_training_loop():
+    """CaptionTrainer (flat buffers, fused loss, HIP Adam) against the oracle forward + torch autograd + torch.optim.Adam
+    on the CPU, 4 steps of the reference's inner loop (train.py:252-262), dropout off."""
+    from capdec.trainer import CaptionTrainer
+    from models.vitcnnattn_model import VITCNNAttentionModel
+    from oracle import decoder_ref as R
+    torch.manual_seed(5)
+    E, V, H, L, B, T = 64, 120, 4, 2, 12, 9
+    m = VITCNNAttentionModel(E, V, H, L, dropout=0.0)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    feats = torch.rand(B, 3048, generator=g)
+    caps = torch.zeros(B, T + 1, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(2, T - 1, (1,), generator=g))
+        caps[b, 0] = 1
+        caps[b, 1:1 + n] = torch.randint(4, V, (n,), generator=g)
+        caps[b, 1 + n] = 2
+    # reference loop on the CPU
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and k != "positional_encoding.pe")
+          for k, v in sd0.items()}
+    opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=1e-3)
+    ref_losses = []
+    for _ in range(4):
+        enc, new = R.head_pair(sd, feats, "fc_vit", 1000, training=True)
+        loss = R.caption_loss(R.decoder_forward(sd, enc, caps[:, :-1], H), caps[:, 1:])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for k, v in new.items():
+            sd[k] = v
+        ref_losses.append(float(loss.detach()))
+    # HIP trainer
+    m = m.cuda()
+    tr = CaptionTrainer(m, lr=1e-3)
+    losses = [tr.step(feats.cuda(), caps.cuda()) for _ in range(4)]
+    losses = [float(l.item()) for l in losses]
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-4 * abs(b), (losses, ref_losses)
+    assert ref_losses[-1] < ref_losses[0]
+    got = m.state_dict()
+    # Parameters after Adam: m / (sqrt(v) + eps) maps every gradient element to a step of about +-lr whatever its
+    # magnitude, so elements whose gradient is at the rounding-noise level (e.g. the key biases, whose gradient is
+    # mathematically zero) may move by up to lr per step in either direction on both sides.  Hence: the bulk must
+    # agree tightly (mean |diff| <= 2e-6), no element may differ by more than the total possible movement.
+    lr, steps = 1e-3, 4
+    for k, v in sd.items():
+        if v.is_floating_point():
+            d = (got[k].detach().cpu().double() - v.detach().double()).abs()
+            assert float(d.max()) <= 2.2 * lr * steps, (k, float(d.max()))
+            # zero-gradient parameters: key biases (softmax shift invariance) and the biases of the projections that
+            # feed the training-mode BatchNorm (a constant shift is removed by the batch mean)
+            # (the running mean follows those projection biases)
+            if not k.endswith(("W_k.bias", "fc_vit.bias", "fc_cnn.bias", "batchnorm.running_mean")):
+                assert float(d.mean()) <= 2e-6, (k, float(d.mean()))
+    assert int(got["batchnorm.num_batches_tracked"]) == 4
