@@ -34,7 +34,7 @@ def _row_stride(t, name):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
-def gemm_groups(groups, K, relu=False):
+def gemm_groups(groups, K, relu=False, extra_flags=0):
     """groups: list of dicts with P,Q,C (2-D, row-contiguous) and optional bias_j,bias_i,scale_j,shift_j,R."""
     lib = _lib.load()
     n = len(groups)
@@ -62,18 +62,21 @@ def gemm_groups(groups, K, relu=False):
             if R.shape != C.shape:
                 raise RuntimeError("capdec gemm: residual shape mismatch")
             g.R, g.ldri, g.ldrj = R.data_ptr(), _row_stride(R, "R"), 1
-    _lib.check(lib.capdec_gemm(arr, n, K, _lib.GEMM_RELU if relu else 0, _stream()), "capdec_gemm")
+    _lib.check(lib.capdec_gemm(arr, n, K, (_lib.GEMM_RELU if relu else 0) | extra_flags, _stream()), "capdec_gemm")
 
 
-def linear(x, W, b=None, relu=False, residual=None, scale=None, shift=None, out=None):
-    """y = x W^T + b with fused epilogue; x [M,K] (row stride free), W [N,K]."""
+def linear(x, W, b=None, relu=False, residual=None, scale=None, shift=None, out=None, split_k=False):
+    """y = x W^T + b with fused epilogue; x [M,K] (row stride free), W [N,K].
+    split_k: split the contraction over workgroups and add the partial sums with float atomics (long K, few
+    output tiles: the 86436-wide YOLO head).  ``out`` must then hold zeros; no relu / residual."""
     _chk(x, name="x")
     _chk(W, name="W")
     M, K = x.shape
     N = W.shape[0]
     if out is None:
-        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
-    gemm_groups([dict(P=x, Q=W, C=out, bias_j=b, R=residual, scale_j=scale, shift_j=shift)], K, relu)
+        out = (torch.zeros if split_k else torch.empty)((M, N), device=x.device, dtype=torch.float32)
+    gemm_groups([dict(P=x, Q=W, C=out, bias_j=b, R=residual, scale_j=scale, shift_j=shift)], K, relu,
+                extra_flags=_lib.GEMM_ATOMIC if split_k else 0)
     return out
 
 
@@ -266,12 +269,14 @@ def linear_dgrad(dy, W, mask=None, accum=None):
 
 
 def linear_wgrad(dy, x, out=None):
-    """dW = dY^T X  (dY [M,N], X [M,K]) -> [N,K]"""
+    """dW += dY^T X  (dY [M,N], X [M,K]) -> [N,K].  The contraction over the M rows is split over workgroups and
+    summed with float atomics, so ``out`` is accumulated into (a fresh zero tensor when omitted)."""
     M, N = dy.shape
     K = x.shape[1]
     if out is None:
-        out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
-    return gemm_raw(dy, x, out, N, K, M, _row_stride(dy, "dy"), _row_stride(x, "x"), _lib.GEMM_TP | _lib.GEMM_TQ)
+        out = torch.zeros((N, K), device=dy.device, dtype=torch.float32)
+    return gemm_raw(dy, x, out, N, K, M, _row_stride(dy, "dy"), _row_stride(x, "x"),
+                    _lib.GEMM_TP | _lib.GEMM_TQ | _lib.GEMM_ATOMIC)
 
 
 def colsum(x, out):

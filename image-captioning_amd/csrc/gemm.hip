@@ -17,115 +17,139 @@
 
 namespace {
 
-constexpr int BK = 32;    // k extent of one staged tile
-constexpr int LDK = 36;   // padded LDS row stride in floats (144 B) of a k-contiguous operand tile
-
 struct GemmKArgs {
     capdec_gemm_group g[4];
     int K;
     int flags;
+    int nsplit;          // k-range splits per group (blockIdx.z = group * nsplit + split); > 1 only with ATOMIC
     capdec_gemm_extra x;
 };
 
-template <int WI, int WJ>
-constexpr int lds_floats() { return 2 * (64 * WI + 64 * WJ) * LDK; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-// One operand tile of NX = 64*W rows (the i or j axis) by BK columns (the contraction axis).
-//  T == false: the operand is stored [row][k] (k contiguous).  LDS image [row][LDK]; a lane reads its four
-//              k values with one ds_read_b128.
+// One operand tile of NX rows (the i or j axis) by BK columns (the contraction axis), staged by THREADS threads.
+//  T == false: the operand is stored [row][k] (k contiguous).  LDS image [row][BK+4]: the padded row stride
+//              (144 B at BK=32, 80 B at BK=16) makes the 16-B fragment reads of 32 rows bank-conflict free;
+//              a lane reads its four k values with one ds_read_b128.
 //  T == true : the operand is stored [k][row] (row contiguous; the contraction runs over its leading
 //              axis, as in dX = dY W and dW = dY^T X).  LDS image [k][NX+4]; a lane reads its four k values
 //              with four ds_read_b32 (32 consecutive floats per half-wave: conflict-free).
-template <int W, bool VEC, bool T>
+template <int NX_, int BK, bool VEC, bool T, int THREADS>
 struct Operand {
-    static constexpr int NX = 64 * W;
-    static constexpr int NR = NX / 32;            // float4 per thread per tile
+    static constexpr int NX = NX_;
+    static constexpr int LDK = BK + 4;
     static constexpr int LDT = NX + 4;
-    static constexpr int NV = NX / 4;             // float4 per k-row when T
-    static constexpr int KPP = 256 / NV;          // k-rows per pass when T
+    static constexpr int TPR = BK / 4;            // threads per row (normal layout)
+    static constexpr int RPP = THREADS / TPR;     // rows per pass (normal layout)
+    static constexpr int NV = NX / 4;             // float4 per k-row (transposed layout)
+    static constexpr int KPP = THREADS / NV;      // k-rows per pass (transposed layout)
+    static constexpr int NR = NX * BK / 4 / THREADS;   // float4 per thread per tile
+    static constexpr int BUF = cmax(NX * LDK, BK * LDT);
+    static_assert(NX % RPP == 0 && BK % KPP == 0 && NR >= 1, "tile does not divide over the threads");
     const float* __restrict__ base;
     int64_t ld;
     int n, K, x0;
-    float* lds;                                   // 2 buffers
-    f32x4 reg[NR];
+    float* lds;                                   // 2 buffers of BUF floats
+    int tid;                                      // thread index inside its k-group
 
-    __device__ __forceinline__ void gload(int kt) {
-        const int tid = threadIdx.x;
+    // Loads are branch-free (addresses clamped into the operand) so that the compiler can keep them in
+    // flight across the MFMAs with counted waits.  Rows past the operand's end receive copies of its
+    // last row: they only feed output rows/columns that are never stored.  Columns past K are zeroed
+    // when the tile is written to LDS (lstore), since they would otherwise enter every dot product.
+    __device__ __forceinline__ void gload(int kt, f32x4 (&reg)[NR]) const {
         if (!T) {
-            const int lrow = tid >> 3, k = kt * BK + (tid & 7) * 4;
+            const int lrow = tid / TPR, k = kt * BK + (tid % TPR) * 4;
 #pragma unroll
             for (int p = 0; p < NR; ++p) {
-                const int row = x0 + lrow + 32 * p;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (row < n) {
-                    const float* q = base + (int64_t)row * ld + k;
-                    if (VEC) {
-                        if (k < K) v = *reinterpret_cast<const f32x4*>(q);
-                    } else {
-                        if (k + 0 < K) v[0] = q[0];
-                        if (k + 1 < K) v[1] = q[1];
-                        if (k + 2 < K) v[2] = q[2];
-                        if (k + 3 < K) v[3] = q[3];
-                    }
+                const int row = min(x0 + lrow + RPP * p, n - 1);
+                const float* q = base + (int64_t)row * ld;
+                if (VEC) {
+                    reg[p] = *reinterpret_cast<const f32x4*>(q + min(k, K - 4));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) reg[p][e] = q[min(k + e, K - 1)];
                 }
-                reg[p] = v;
             }
         } else {
             const int iv = tid % NV, kr = tid / NV;
             const int row = x0 + 4 * iv;
 #pragma unroll
             for (int p = 0; p < NR; ++p) {
-                const int k = kt * BK + kr + KPP * p;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k < K) {
-                    const float* q = base + (int64_t)k * ld + row;
-                    if (VEC && row + 3 < n) {
-                        v = *reinterpret_cast<const f32x4*>(q);
-                    } else {
-                        if (row + 0 < n) v[0] = q[0];
-                        if (row + 1 < n) v[1] = q[1];
-                        if (row + 2 < n) v[2] = q[2];
-                        if (row + 3 < n) v[3] = q[3];
-                    }
+                const int k = min(kt * BK + kr + KPP * p, K - 1);
+                const float* q = base + (int64_t)k * ld;
+                if (VEC) {   // n % 4 == 0 here: a vector never straddles the operand's end
+                    reg[p] = *reinterpret_cast<const f32x4*>(q + min(row, n - 4));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) reg[p][e] = q[min(row + e, n - 1)];
                 }
-                reg[p] = v;
             }
         }
     }
-    __device__ __forceinline__ void lstore(int buf) {
-        const int tid = threadIdx.x;
+    __device__ __forceinline__ void lstore(int buf, int kt, const f32x4 (&reg)[NR]) const {
         if (!T) {
-            const int lrow = tid >> 3, lk = (tid & 7) * 4;
+            const int lrow = tid / TPR, lk = (tid % TPR) * 4;
+            const int k = kt * BK + lk;
 #pragma unroll
-            for (int p = 0; p < NR; ++p)
-                *reinterpret_cast<f32x4*>(&lds[(buf * NX + lrow + 32 * p) * LDK + lk]) = reg[p];
+            for (int p = 0; p < NR; ++p) {
+                f32x4 v = reg[p];
+                if (VEC) {
+                    if (k >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e >= K) v[e] = 0.f;
+                }
+                *reinterpret_cast<f32x4*>(&lds[buf * BUF + (lrow + RPP * p) * LDK + lk]) = v;
+            }
         } else {
             const int iv = tid % NV, kr = tid / NV;
 #pragma unroll
-            for (int p = 0; p < NR; ++p)
-                *reinterpret_cast<f32x4*>(&lds[(buf * BK + kr + KPP * p) * LDT + 4 * iv]) = reg[p];
+            for (int p = 0; p < NR; ++p) {
+                f32x4 v = reg[p];
+                if (kt * BK + kr + KPP * p >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&lds[buf * BUF + (kr + KPP * p) * LDT + 4 * iv]) = v;
+            }
         }
     }
     // the four k values {kc*8 + 4h + m} of row (w0 + r) for the lane (r, h)
     __device__ __forceinline__ f32x4 frag(int buf, int w0, int kc, int r, int h) const {
-        if (!T) return *reinterpret_cast<const f32x4*>(&lds[(buf * NX + w0 + r) * LDK + kc * 8 + 4 * h]);
-        const float* q = &lds[(buf * BK + kc * 8 + 4 * h) * LDT + w0 + r];
+        if (!T) return *reinterpret_cast<const f32x4*>(&lds[buf * BUF + (w0 + r) * LDK + kc * 8 + 4 * h]);
+        const float* q = &lds[buf * BUF + (kc * 8 + 4 * h) * LDT + w0 + r];
         return f32x4{q[0], q[LDT], q[2 * LDT], q[3 * LDT]};
     }
 };
 
-// Accumulate the (i0, j0) tile into acc.  Ends with every wave past the last barrier, so the caller
-// may reuse `lds` right away.
-template <int WI, int WJ, bool VEC, bool TP = false, bool TQ = false>
+// workgroup = KG k-groups of (WM x 2) wavefronts; tile = (32*WM*WI) x (64*WJ)
+template <int WM, int WI, int WJ, int BK, bool TP, bool TQ, int KG>
+constexpr int lds_floats() {
+    return KG * 2 * (Operand<32 * WM * WI, BK, true, TP, 128 * WM>::BUF + Operand<64 * WJ, BK, true, TQ, 128 * WM>::BUF);
+}
+
+// Accumulate k-tiles [kt0, kt1) of the (i0, j0) tile into acc.  Global loads run TWO tiles ahead of the
+// MFMAs (two register sets, statically named), LDS is double buffered, one barrier per tile.
+// A k-group is WM x 2 wavefronts (each owning WI x WJ accumulators of 32x32) on a (32*WM*WI) x (64*WJ) tile.
+// KG > 1: the workgroup holds KG such groups; group g takes the k-tiles kt0+g, kt0+g+KG, ... into its own LDS
+// buffers and the partial tiles are summed through LDS into group 0 at the end.  With WM = 1, KG = 2 a
+// 256-thread workgroup covers a 32x64 tile: twice the workgroups of the 64x64 form, for problems whose grid
+// would otherwise leave CUs idle (the MFMA pipe is per CU, so only more workgroups shorten such a launch).
+// Ends with every wave past the last barrier, so the caller may reuse `lds` right away.
+template <int WM, int WI, int WJ, int BK, bool VEC, bool TP = false, bool TQ = false, int KG = 1>
 __device__ __forceinline__ void mainloop(const float* __restrict__ P, const float* __restrict__ Q, int64_t ldp,
-                                         int64_t ldq, int I, int J, int K, int i0, int j0, float* lds,
-                                         f32x16 (&acc)[WI][WJ]) {
-    constexpr int BI = 64 * WI;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
+                                         int64_t ldq, int I, int J, int K, int i0, int j0, int kt0, int kt1,
+                                         float* lds, f32x16 (&acc)[WI][WJ]) {
+    constexpr int GT = 128 * WM;                  // threads per k-group
+    using OpP = Operand<32 * WM * WI, BK, VEC, TP, GT>;
+    using OpQ = Operand<64 * WJ, BK, VEC, TQ, GT>;
+    constexpr int GROUP_LDS = 2 * (OpP::BUF + OpQ::BUF);
+    const int kg = KG > 1 ? (int)(threadIdx.x / GT) : 0;
+    const int tid = threadIdx.x % GT;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wi = WM == 2 ? wave >> 1 : 0, wj = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    Operand<WI, VEC, TP> op{P, ldp, I, K, i0, lds};
-    Operand<WJ, VEC, TQ> oq{Q, ldq, J, K, j0, lds + 2 * BI * LDK};
+    float* glds = lds + kg * GROUP_LDS;
+    const OpP op{P, ldp, I, K, i0, glds, tid};
+    const OpQ oq{Q, ldq, J, K, j0, glds + 2 * OpP::BUF, tid};
 
 #pragma unroll
     for (int ti = 0; ti < WI; ++ti)
@@ -133,27 +157,16 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ P, const floa
         for (int tj = 0; tj < WJ; ++tj)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[ti][tj][e] = 0.f;
+    if (kt0 >= kt1) return;
 
-    const int nk = (K + BK - 1) / BK;
-    op.gload(0);
-    oq.gload(0);
-    op.lstore(0);
-    oq.lstore(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            op.gload(kt + 1);
-            oq.gload(kt + 1);
-        }
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             f32x4 a[WI], b[WJ];
 #pragma unroll
-            for (int ti = 0; ti < WI; ++ti) a[ti] = op.frag(cur, wi * 32 * WI + ti * 32, kc, r, h);
+            for (int ti = 0; ti < WI; ++ti) a[ti] = op.frag(buf, wi * 32 * WI + ti * 32, kc, r, h);
 #pragma unroll
-            for (int tj = 0; tj < WJ; ++tj) b[tj] = oq.frag(cur, wj * 32 * WJ + tj * 32, kc, r, h);
+            for (int tj = 0; tj < WJ; ++tj) b[tj] = oq.frag(buf, wj * 32 * WJ + tj * 32, kc, r, h);
             // lane half h feeds k = kc*8 + 4h + m, so MFMA m sums k in {kc*8+m, kc*8+4+m}
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -163,31 +176,94 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ P, const floa
                     for (int tj = 0; tj < WJ; ++tj)
                         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][m], b[tj][m], acc[ti][tj], 0, 0, 0);
         }
-        if (more) {
-            op.lstore(cur ^ 1);
-            oq.lstore(cur ^ 1);
+    };
+
+    f32x4 pa[OpP::NR], qa[OpQ::NR], pb[OpP::NR], qb[OpQ::NR];   // register sets A and B
+    const int last = kt1 - 1;
+    const int nit = (kt1 - kt0 + KG - 1) / KG;   // the same trip count in every k-group (shared barriers)
+    // this group's it-th tile; indices past the range are clamped to the last tile for the loads (redundant,
+    // never multiplied), which keeps the loop body free of branches around memory operations
+    auto tile = [&](int it) { return kt0 + kg + it * KG; };
+    op.gload(min(tile(0), last), pa);
+    oq.gload(min(tile(0), last), qa);
+    op.gload(min(tile(1), last), pb);
+    oq.gload(min(tile(1), last), qb);
+    op.lstore(0, min(tile(0), last), pa);
+    oq.lstore(0, min(tile(0), last), qa);
+    __syncthreads();
+    for (int it = 0; it < nit; it += 2) {
+        // tile it is in LDS[0]; set B holds tile it+1; fetch tile it+2 into set A
+        // (the scheduling fences keep the compiler from sinking the loads below the MFMAs)
+        op.gload(min(tile(it + 2), last), pa);
+        oq.gload(min(tile(it + 2), last), qa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (KG == 1 || tile(it) <= last) compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        op.lstore(1, min(tile(it + 1), last), pb);
+        oq.lstore(1, min(tile(it + 1), last), qb);
+        __syncthreads();
+        if (it + 1 >= nit) break;
+        // tile it+1 is in LDS[1]; set A holds tile it+2; fetch tile it+3 into set B
+        op.gload(min(tile(it + 3), last), pb);
+        oq.gload(min(tile(it + 3), last), qb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (KG == 1 || tile(it + 1) <= last) compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        op.lstore(0, min(tile(it + 2), last), pa);
+        oq.lstore(0, min(tile(it + 2), last), qa);
+        __syncthreads();
+    }
+    if (KG > 1) {
+        // sum the k-groups' partial tiles into group 0: [group-1][wave][register][lane] floats
+        float* red = lds;
+        constexpr int PER_WAVE = WI * WJ * 16 * 64;
+        if (kg > 0) {
+            float* dst = red + ((kg - 1) * 2 * WM + wave) * PER_WAVE + lane;
+#pragma unroll
+            for (int ti = 0; ti < WI; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < WJ; ++tj)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[((ti * WJ + tj) * 16 + e) * 64] = acc[ti][tj][e];
         }
         __syncthreads();
-        cur ^= 1;
+        if (kg == 0) {
+#pragma unroll
+            for (int g = 1; g < KG; ++g) {
+                const float* src = red + ((g - 1) * 2 * WM + wave) * PER_WAVE + lane;
+#pragma unroll
+                for (int ti = 0; ti < WI; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < WJ; ++tj)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[ti][tj][e] += src[((ti * WJ + tj) * 16 + e) * 64];
+            }
+        }
     }
 }
 
 // accumulator register e of lane-half h is row (e&3) + 8*(e>>2) + 4*h of the 32x32 tile
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
-template <int WI, int WJ, bool VEC, bool TP, bool TQ>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs args) {
+template <int WM, int WI, int WJ, int BK, bool VEC, bool TP, bool TQ, int KG>
+__global__ __launch_bounds__(128 * WM * KG) void gemm_kernel(GemmKArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const capdec_gemm_group& g = args.g[blockIdx.z];
-    constexpr int BI = 64 * WI, BJ = 64 * WJ;
+    const int grp = blockIdx.z / args.nsplit, split = blockIdx.z - grp * args.nsplit;
+    const capdec_gemm_group& g = args.g[grp];
+    constexpr int BI = 32 * WM * WI, BJ = 64 * WJ;
     const int i0 = blockIdx.y * BI, j0 = blockIdx.x * BJ;
     if (i0 >= g.I || j0 >= g.J) return;   // groups of different size share the grid
+    const int nk = (args.K + BK - 1) / BK;
+    const int per = (nk + args.nsplit - 1) / args.nsplit;
+    const int kt0 = split * per, kt1 = min(nk, kt0 + per);
     f32x16 acc[WI][WJ];
-    mainloop<WI, WJ, VEC, TP, TQ>(g.P, g.Q, g.ldp, g.ldq, g.I, g.J, args.K, i0, j0, lds, acc);
+    mainloop<WM, WI, WJ, BK, VEC, TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, g.I, g.J, args.K, i0, j0, kt0, kt1, lds, acc);
+    if (KG > 1 && threadIdx.x >= 128 * WM) return;   // group 0 holds the summed tile
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
+    const int wi = WM == 2 ? wave >> 1 : 0, wj = wave & 1, r = lane & 31, h = lane >> 5;
     const bool relu = (args.flags & CAPDEC_GEMM_RELU) != 0;
+    const bool atomic = (args.flags & CAPDEC_GEMM_ATOMIC) != 0;
     const capdec_gemm_extra& x = args.x;
 #pragma unroll
     for (int tj = 0; tj < WJ; ++tj) {
@@ -202,6 +278,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs args) {
             for (int e = 0; e < 16; ++e) {
                 const int i = i0 + wi * 32 * WI + ti * 32 + acc_row(e, h);
                 if (i >= g.I) continue;
+                float* c = &g.C[(int64_t)i * g.ldci + (int64_t)j * g.ldcj];
+                if (atomic) {
+                    // C += partial; the affine terms (bias, BatchNorm shift) enter once, with the first k-range
+                    float v = acc[ti][tj][e];
+                    if (split == 0) {
+                        v += bj;
+                        if (g.bias_i) v += g.bias_i[i];
+                    }
+                    if (g.scale_j) v = v * sc + (split == 0 ? sh : 0.f);
+                    atomicAdd(c, v);
+                    continue;
+                }
                 float v = acc[ti][tj][e] + bj;
                 if (g.bias_i) v += g.bias_i[i];
                 if (g.scale_j) v = v * sc + sh;
@@ -213,7 +301,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs args) {
                 }
                 if (x.mask && !(x.mask[(int64_t)i * x.ldm + j] > 0.f)) v = 0.f;
                 if (g.R) v += g.R[(int64_t)i * g.ldri + (int64_t)j * g.ldrj];
-                g.C[(int64_t)i * g.ldci + (int64_t)j * g.ldcj] = v;
+                *c = v;
             }
         }
     }
@@ -221,7 +309,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs args) {
 
 // ---- vocabulary projection with lane-local reductions over the vocabulary axis -------------------
 // P = W [V,K] (i = vocabulary id), Q = x [M,K] (j = row).  MODE 0: arg-max; MODE 1: (max, sum exp).
-template <int WI, int WJ, bool VEC, int MODE>
+template <int WI, int WJ, int BK, bool VEC, int MODE>
 __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restrict__ W, const float* __restrict__ x,
                                                            int64_t ldx, const float* __restrict__ bias, int V, int M,
                                                            int K, float* __restrict__ out_a, void* __restrict__ out_b,
@@ -230,7 +318,7 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restri
     constexpr int BI = 64 * WI, BJ = 64 * WJ;
     const int i0 = blockIdx.y * BI, j0 = blockIdx.x * BJ;
     f32x16 acc[WI][WJ];
-    mainloop<WI, WJ, VEC>(W, x, (int64_t)K, ldx, V, M, K, i0, j0, lds, acc);
+    mainloop<2, WI, WJ, BK, VEC>(W, x, (int64_t)K, ldx, V, M, K, i0, j0, 0, (K + BK - 1) / BK, lds, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
@@ -376,24 +464,49 @@ bool allow_lds(F* kernel, size_t bytes) {
                                (int)bytes) == hipSuccess;
 }
 
-template <int WI, int WJ, bool TP, bool TQ>
-int launch_gemm_cfg(const GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hipStream_t s) {
-    dim3 grid((maxJ + 64 * WJ - 1) / (64 * WJ), (maxI + 64 * WI - 1) / (64 * WI), ngroups);
-    constexpr size_t smem = lds_floats<WI, WJ>() * sizeof(float);
-    static const bool ready = allow_lds(gemm_kernel<WI, WJ, true, TP, TQ>, smem) &&
-                              allow_lds(gemm_kernel<WI, WJ, false, TP, TQ>, smem);
+template <int WM, int WI, int WJ, int BK, bool TP, bool TQ, int KG>
+int launch_gemm_cfg(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hipStream_t s) {
+    constexpr int BI = 32 * WM * WI, BJ = 64 * WJ, NT = 128 * WM * KG;
+    const int ti = (maxI + BI - 1) / BI, tj = (maxJ + BJ - 1) / BJ;
+    const int nk = (a.K + BK - 1) / BK;
+    a.nsplit = 1;
+    if (a.flags & CAPDEC_GEMM_ATOMIC) {
+        // split the contraction until about four workgroups per CU exist, at least 4 k-tiles per split
+        const long tiles = (long)ti * tj * ngroups;
+        long want = (1024 + tiles - 1) / tiles;
+        const long cap = nk / 4 > 0 ? nk / 4 : 1;
+        a.nsplit = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+        if (a.nsplit > 64) a.nsplit = 64;
+    }
+    dim3 grid(tj, ti, ngroups * a.nsplit);
+    constexpr size_t smem = lds_floats<WM, WI, WJ, BK, TP, TQ, KG>() * sizeof(float);
+    static const bool ready = allow_lds(gemm_kernel<WM, WI, WJ, BK, true, TP, TQ, KG>, smem) &&
+                              allow_lds(gemm_kernel<WM, WI, WJ, BK, false, TP, TQ, KG>, smem);
     if (!ready) return CAPDEC_EINVAL;
-    if (vec) hipLaunchKernelGGL((gemm_kernel<WI, WJ, true, TP, TQ>), grid, dim3(256), smem, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<WI, WJ, false, TP, TQ>), grid, dim3(256), smem, s, a);
+    if (vec) hipLaunchKernelGGL((gemm_kernel<WM, WI, WJ, BK, true, TP, TQ, KG>), grid, dim3(NT), smem, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WI, WJ, BK, false, TP, TQ, KG>), grid, dim3(NT), smem, s, a);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
 
+// Tile choice.  cfg = 0: automatic; otherwise force: 11 / 22 / 216 = 64x64 (BK 32), 128x128 (BK 32), 128x128 (BK 16);
+// 32 = 32x64 tile with the k-loop split over the workgroup's two wave pairs.
+int g_force_cfg = 0;
+
 template <bool TP, bool TQ>
-int launch_gemm_layout(const GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hipStream_t s) {
-    const long tiles128 = (long)((maxI + 127) / 128) * ((maxJ + 127) / 128) * ngroups;
-    if (tiles128 >= 192) return launch_gemm_cfg<2, 2, TP, TQ>(a, ngroups, maxI, maxJ, vec, s);
-    return launch_gemm_cfg<1, 1, TP, TQ>(a, ngroups, maxI, maxJ, vec, s);
+int launch_gemm_layout(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hipStream_t s) {
+    int cfg = g_force_cfg;
+    if (cfg == 0) {
+        // 64x64 tiles at four workgroups per CU hide latency best at every size measured; when that grid would
+        // leave CUs idle (fewer than two tiles per CU), halve the tile so twice as many CUs share the MFMA work
+        const long tiles64 = (long)((maxI + 63) / 64) * ((maxJ + 63) / 64) * ngroups;
+        const bool atomic = (a.flags & CAPDEC_GEMM_ATOMIC) != 0;
+        cfg = (!atomic && tiles64 < 512) ? 32 : 11;
+    }
+    if (cfg == 22) return launch_gemm_cfg<2, 2, 2, 32, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
+    if (cfg == 216) return launch_gemm_cfg<2, 2, 2, 16, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
+    if (cfg == 32) return launch_gemm_cfg<1, 1, 1, 32, TP, TQ, 2>(a, ngroups, maxI, maxJ, vec, s);
+    return launch_gemm_cfg<2, 1, 1, 32, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
 }
 
 constexpr int VOCAB_BI = 128;   // vocabulary ids per tile of the fused projections
@@ -424,16 +537,27 @@ int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int 
         if (g.I > maxI) maxI = g.I;
         if (g.J > maxJ) maxJ = g.J;
         vec = vec && capdec_aligned16(g.P) && capdec_aligned16(g.Q) && g.ldp % 4 == 0 && g.ldq % 4 == 0;
+        if (tp) vec = vec && g.I % 4 == 0;     // a 16-byte load along a row-contiguous operand must not straddle its end
+        if (tq) vec = vec && g.J % 4 == 0;
     }
-    if (!tp || !tq) vec = vec && (K % 4 == 0);   // a k-contiguous operand is read four k at a time
+    if (!tp || !tq) vec = vec && (K % 4 == 0) && K >= 4;   // a k-contiguous operand is read four k at a time
     for (int n = ngroups; n < 4; ++n) a.g[n] = a.g[0];
     if (maxI == 0 || maxJ == 0) return 0;
+    if ((flags & CAPDEC_GEMM_ATOMIC) && ((flags & CAPDEC_GEMM_RELU) || a.x.mask || a.x.lse)) return CAPDEC_EINVAL;
+    for (int n = 0; n < ngroups; ++n)
+        if ((flags & CAPDEC_GEMM_ATOMIC) && groups[n].R) return CAPDEC_EINVAL;
     if (tp) return launch_gemm_layout<true, true>(a, ngroups, maxI, maxJ, vec, s);
     if (tq) return launch_gemm_layout<false, true>(a, ngroups, maxI, maxJ, vec, s);
     return launch_gemm_layout<false, false>(a, ngroups, maxI, maxJ, vec, s);
 }
 
 extern "C" {
+
+int capdec_gemm_force_config(int cfg) {
+    CAPDEC_REQUIRE(cfg == 0 || cfg == 11 || cfg == 22 || cfg == 216 || cfg == 32);
+    g_force_cfg = cfg;
+    return 0;
+}
 
 int capdec_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, void* stream) {
     return capdec_launch_gemm(groups, ngroups, K, flags, (hipStream_t)stream, nullptr);
@@ -454,16 +578,14 @@ static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const floa
     const bool vec = (K % 4 == 0) && (ldx % 4 == 0) && capdec_aligned16(x) && capdec_aligned16(W);
     // samples sit on the j (lane) axis: 128-wide tiles when there are enough rows to fill the chip
     const bool wide = ((long)nt * ((M + 127) / 128) >= 192);
-    const size_t smem = (wide ? lds_floats<2, 2>() : lds_floats<2, 1>()) * sizeof(float);
-    static const bool ready = allow_lds(vocab_reduce_kernel<2, 2, true, 0>, lds_floats<2, 2>() * sizeof(float)) &&
-                              allow_lds(vocab_reduce_kernel<2, 2, false, 0>, lds_floats<2, 2>() * sizeof(float)) &&
-                              allow_lds(vocab_reduce_kernel<2, 2, true, 1>, lds_floats<2, 2>() * sizeof(float)) &&
-                              allow_lds(vocab_reduce_kernel<2, 2, false, 1>, lds_floats<2, 2>() * sizeof(float));
-    if (!ready) return CAPDEC_EINVAL;
+    constexpr int VBK = 16;   // 128x128 tile at BK 16: 40 KiB of LDS, three workgroups per CU
+    constexpr size_t smem_w = lds_floats<2, 2, 2, VBK, false, false, 1>() * sizeof(float);
+    constexpr size_t smem_n = lds_floats<2, 2, 1, VBK, false, false, 1>() * sizeof(float);
+    const size_t smem = wide ? smem_w : smem_n;
     dim3 grid(wide ? (M + 127) / 128 : (M + 63) / 64, nt, 1);
-#define CAPDEC_VR(WJ_, VEC_, MODE_)                                                                               \
-    hipLaunchKernelGGL((vocab_reduce_kernel<2, WJ_, VEC_, MODE_>), grid, dim3(256), smem, s, W, x, ldx, bias, V, M, \
-                       K, out_a, out_b, nt)
+#define CAPDEC_VR(WJ_, VEC_, MODE_)                                                                                    \
+    hipLaunchKernelGGL((vocab_reduce_kernel<2, WJ_, VBK, VEC_, MODE_>), grid, dim3(256), smem, s, W, x, ldx, bias, V, \
+                       M, K, out_a, out_b, nt)
     if (mode == 0) {
         if (wide) { if (vec) CAPDEC_VR(2, true, 0); else CAPDEC_VR(2, false, 0); }
         else      { if (vec) CAPDEC_VR(1, true, 0); else CAPDEC_VR(1, false, 0); }

@@ -59,6 +59,11 @@ typedef struct capdec_gemm_group {
 #define CAPDEC_GEMM_RELU 1
 #define CAPDEC_GEMM_TP 2     /* P is stored [K, I] (element (i,k) at P[k*ldp + i]); needs TQ as well   */
 #define CAPDEC_GEMM_TQ 4     /* Q is stored [K, J] (element (j,k) at Q[k*ldq + j])                      */
+#define CAPDEC_GEMM_ATOMIC 8 /* C += result with float atomics; the contraction may then be split over     */
+                             /* workgroups (small I x J, long K: weight gradients, wide feature heads).    */
+                             /* C must hold the value to add to (zero it for a plain product); only bias   */
+                             /* and scale/shift epilogues are allowed; sums differ in the last bits from    */
+                             /* run to run (arrival order).                                                 */
 int capdec_gemm(const capdec_gemm_group* groups /*host*/, int ngroups, int K, int flags, void* stream);
 
 /* Backward forms of nn.Linear y = x W^T + b (autograd of the same reference lines) use the layout flags:
@@ -74,6 +79,9 @@ typedef struct capdec_gemm_extra {
     const float* mask; int64_t ldm;
     const float* lse; const int64_t* tgt; const float* gscale; int64_t ignore_index;
 } capdec_gemm_extra;
+/* Tuning hook for benchmarks: 0 = automatic tile choice, 11 = 64x64 (BK 32), 22 = 128x128 (BK 32), 216 = 128x128 (BK 16),
+ * 32 = 32x64 tile with its k-loop split over the two wave pairs.  Process-wide; not for production use. */
+int capdec_gemm_force_config(int cfg);
 int capdec_gemm_ex(const capdec_gemm_group* groups /*host*/, int ngroups, int K, int flags,
                    const capdec_gemm_extra* extra /*host, nullable*/, void* stream);
 

@@ -363,3 +363,28 @@ def test_full_size_decode_cfg2(S):
     exact, _ = _greedy(dec, enc[256:320], 20, exact=True)
     check_greedy(exact, sd, enc[256:320], 4, 20, want_rows=sub, tol=REL)
     assert sum(a != b for a, b in zip(sub, got[256:320])) <= 1   # batch-size independent up to a near-tie
+
+
+def test_gemm_split_k_atomic_and_forced_tiles(ops):
+    """Long contraction split over workgroups (float atomics) and every tile configuration of the kernel."""
+    from capdec import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(96, 9000, generator=g)
+    W = torch.randn(80, 9000, generator=g)
+    b, sc, sh = torch.randn(80, generator=g), torch.rand(80, generator=g) + 0.5, torch.randn(80, generator=g)
+    ref = (x.double() @ W.double().t() + b.double()) * sc.double() + sh.double()
+    try:
+        for cfg in (0, 11, 32, 22, 216):
+            lib.capdec_gemm_force_config(cfg)
+            y = ops.linear(x.cuda(), W.cuda(), b.cuda(), scale=sc.cuda(), shift=sh.cuda(), split_k=True)
+            close(y, ref, what=f"split-k cfg {cfg}")
+            y2 = ops.linear(x.cuda(), W.cuda(), b.cuda(), relu=True)
+            close(y2, torch.relu(x.double() @ W.double().t() + b.double()), what=f"plain cfg {cfg}")
+            dy = torch.randn(300, 70, generator=g)
+            xx = torch.randn(300, 130, generator=g)
+            close(ops.linear_wgrad(dy.cuda(), xx.cuda()), dy.double().t() @ xx.double(), what=f"wgrad cfg {cfg}")
+            Wd = torch.randn(70, 130, generator=g)
+            close(ops.linear_dgrad(dy.cuda(), Wd.cuda()), dy.double() @ Wd.double(), what=f"dgrad cfg {cfg}")
+    finally:
+        lib.capdec_gemm_force_config(0)
