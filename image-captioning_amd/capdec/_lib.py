@@ -22,12 +22,12 @@ class GemmGroup(Structure):
     _fields_ = [("P", c_void_p), ("Q", c_void_p), ("C", c_void_p), ("bias_i", c_void_p), ("bias_j", c_void_p),
                 ("scale_j", c_void_p), ("shift_j", c_void_p), ("R", c_void_p),
                 ("ldp", c_int64), ("ldq", c_int64), ("ldci", c_int64), ("ldcj", c_int64), ("ldri", c_int64),
-                ("ldrj", c_int64), ("I", c_int32), ("J", c_int32)]
+                ("ldrj", c_int64), ("I", c_int32), ("J", c_int32), ("c_rows", c_void_p)]
 
 
 class GemmExtra(Structure):
     _fields_ = [("mask", c_void_p), ("ldm", c_int64), ("lse", c_void_p), ("tgt", c_void_p), ("gscale", c_void_p),
-                ("ignore_index", c_int64)]
+                ("ignore_index", c_int64), ("rows_dev", c_void_p)]
 
 
 class AttnW(Structure):
@@ -84,9 +84,9 @@ _SIGNATURES = {
     "capdec_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "capdec_bn_fold": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
     "capdec_bn_train_forward": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, c_int, c_int, _P, _P, _P, _P]),
-    "capdec_tf_decode_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int]),
-    "capdec_tf_greedy_decode": (c_int, [POINTER(TfModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t,
-                                        _P, _P, _P, POINTER(Probe), _P]),
+    "capdec_tf_decode_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int, c_int]),
+    "capdec_tf_greedy_decode": (c_int, [POINTER(TfModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                        c_size_t, _P, _P, _P, POINTER(Probe), _P]),
     "capdec_event_create": (c_int, [POINTER(c_void_p)]),
     "capdec_event_destroy": (c_int, [_P]),
     "capdec_event_record": (c_int, [_P, _P]),

@@ -91,7 +91,7 @@ class VocabProbe:
 
 
 def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=False, resolve_dirty=True, probe=None,
-                  to_cpu=True):
+                  to_cpu=True, extra_cap=0):
     """Greedy decode on the GPU.  enc [B,S,E] fp32.  Returns (ids int64 [B,max_length] padded with -1, lengths
     int32 [B], number of rows that went through the exact path).  ids/lengths are CPU tensors unless
     ``to_cpu=False`` (then they stay on the device, e.g. for a cross-rank gather)."""
@@ -114,13 +114,13 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
                 n_dirty = B
             else:
                 dirty = torch.empty((B,), dtype=torch.int32, device=dev)
-                nbytes = lib.capdec_tf_decode_workspace_bytes(ctypes.byref(ref.c), B, S, max_length)
+                nbytes = lib.capdec_tf_decode_workspace_bytes(ctypes.byref(ref.c), B, S, max_length, extra_cap)
                 if nbytes == 0:
                     raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
                 ws = _workspace(nbytes, dev)
                 flags = _lib.DECODE_NO_S1_SHORTCUT if no_s1_shortcut else 0
                 _lib.check(lib.capdec_tf_greedy_decode(ctypes.byref(ref.c), enc.data_ptr(), B, S, max_length, sos, eos,
-                                                       flags, ws.data_ptr(), ws.numel(), out_ids.data_ptr(),
+                                                       flags, extra_cap, ws.data_ptr(), ws.numel(), out_ids.data_ptr(),
                                                        out_len.data_ptr(), dirty.data_ptr(),
                                                        ctypes.byref(probe.c) if probe else None, _stream()),
                            "capdec_tf_greedy_decode")
@@ -128,8 +128,8 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
                     rows = torch.nonzero(dirty.cpu(), as_tuple=False).flatten()   # the one host sync of the decode
                     n_dirty = int(rows.numel())
                     if n_dirty:
-                        # a generated <PAD> makes that position's activations depend on the current length
-                        # (transformer.py:117-123: PAD masks the query row); redo those rows on the exact path
+                        # samples whose <PAD>-induced re-run rows did not fit the step's row list (see capdec.h):
+                        # redo those samples on the exact full-prefix path
                         rows = rows.to(dev)
                         sub = enc.index_select(0, rows).contiguous()
                         ids2 = torch.empty((n_dirty, max_length), dtype=torch.int64, device=dev)

@@ -166,21 +166,32 @@ extern "C" {
 // =================================================================================================
 // KV-cached greedy decode
 // =================================================================================================
+// Rows of a step.  Row r < B is the new position t of sample r.  Rows r >= B re-run earlier positions of the few
+// samples that have generated <PAD>: the reference masks a PAD *query row*, which then attends uniformly over the
+// CURRENT length, so from the first PAD position p0 on, every position p0..t-1 of that sample changes with each
+// step (transformer.py:117-123) and is recomputed here through the same kernels, its k/v written back to the cache.
+// rowmap[t][r] = b * max_len + position; nrows[t] = B + number of such rows (device side: the host never sees it).
 struct DecodeWs {
-    float *x, *y, *x1, *x2, *q, *ao, *hb;
+    float *x, *y, *x1, *x2, *q, *ao, *hb;   // [Mcap][E], Mcap = B + extra_cap
     float *kc, *vc;          // [L][B][max_len][E]
     float *ck, *cv;          // [L][B*S][E]
     float *cc;               // [L][B][E]  S == 1: the whole cross-attention block output per sample
     float* pval; int32_t* pidx;
-    int32_t *tok, *done;
+    int32_t *tok, *done, *first_pad;
+    int32_t *rowmap;         // [max_len][Mcap]
+    int32_t *nrows;          // [max_len + 1]
 };
 
-static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, void* base, DecodeWs* w) {
+static int default_extra_cap(int B) { return ((B / 4 > 64 ? B / 4 : 64) + 63) / 64 * 64; }
+
+static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, int extra_cap, void* base,
+                           DecodeWs* w) {
     Carver c(base);
     const size_t BE = (size_t)B * m->E;
+    const size_t ME = (size_t)(B + extra_cap) * m->E;
     DecodeWs d;
-    d.x = c.take<float>(BE); d.y = c.take<float>(BE); d.x1 = c.take<float>(BE); d.x2 = c.take<float>(BE);
-    d.q = c.take<float>(BE); d.ao = c.take<float>(BE); d.hb = c.take<float>(BE);
+    d.x = c.take<float>(ME); d.y = c.take<float>(ME); d.x1 = c.take<float>(ME); d.x2 = c.take<float>(ME);
+    d.q = c.take<float>(ME); d.ao = c.take<float>(ME); d.hb = c.take<float>(ME);
     d.kc = c.take<float>((size_t)m->L * BE * max_len);
     d.vc = c.take<float>((size_t)m->L * BE * max_len);
     d.ck = c.take<float>((size_t)m->L * BE * S);
@@ -191,13 +202,98 @@ static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, 
     d.pidx = c.take<int32_t>((size_t)B * nt);
     d.tok = c.take<int32_t>((size_t)B * (max_len + 1));
     d.done = c.take<int32_t>((size_t)B);
+    d.first_pad = c.take<int32_t>((size_t)B);
+    d.rowmap = c.take<int32_t>((size_t)max_len * (B + extra_cap));
+    d.nrows = c.take<int32_t>((size_t)max_len + 1);
     if (w) *w = d;
     return c.off;
 }
 
-size_t capdec_tf_decode_workspace_bytes(const capdec_tf_model* m, int B, int S, int max_len) {
-    if (check_model(m) != 0 || B < 0 || S < 1 || max_len < 1) return 0;
-    return carve_decode(m, B, S, max_len, nullptr, nullptr);
+__global__ void cached_init_kernel(int32_t* tok, int64_t ldtok, int32_t* done, int32_t* first_pad, int64_t* out_ids,
+                                   int32_t* out_len, int32_t* dirty, int32_t* rowmap, int32_t* nrows, int B,
+                                   int max_len, int sos) {
+    const int n = B * max_len;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int idx = tid; idx < n; idx += nth) out_ids[idx] = -1;
+    for (int b = tid; b < B; b += nth) {
+        tok[(int64_t)b * ldtok] = sos;
+        done[b] = 0;
+        first_pad[b] = INT_MAX;
+        out_len[b] = 0;
+        if (dirty) dirty[b] = 0;
+        rowmap[b] = b * max_len;            // step 0: position 0 of every sample
+    }
+    for (int t = tid; t <= max_len; t += nth) nrows[t] = B;
+}
+
+// One wavefront per sample: pick the token (as greedy_advance_kernel), then prepare step t+1: the sample's new row and,
+// if it holds a <PAD> and is still running, one re-run row per position from the first PAD on.
+__global__ __launch_bounds__(256) void cached_advance_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
+                                                             int B, int ntiles, int t, int max_len, int eos,
+                                                             int32_t* tok, int64_t ldtok, int32_t* done,
+                                                             int32_t* first_pad, int64_t* out_ids, int32_t* out_len,
+                                                             int32_t* dirty, const float* __restrict__ emb,
+                                                             const float* __restrict__ pe, int E, int V,
+                                                             float* __restrict__ x_next, int32_t* rowmap_next,
+                                                             int32_t* nrows_next, int extra_cap) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    float v = -INFINITY;
+    int i = INT_MAX;
+    for (int n = lane; n < ntiles; n += 64) argmax_merge(v, i, pv[(int64_t)b * ntiles + n], pi[(int64_t)b * ntiles + n]);
+    wave_argmax(v, i);
+    if (i < 0 || i >= V) i = 0;   // all-NaN row: no finite winner
+    int p0 = INT_MAX, running = 0, base = 0;
+    if (lane == 0) {
+        tok[(int64_t)b * ldtok + t + 1] = i;
+        if (!done[b]) {
+            if (i == eos) {
+                done[b] = 1;
+            } else {
+                const int n = out_len[b];
+                out_ids[(int64_t)b * max_len + n] = i;
+                out_len[b] = n + 1;
+                if (i == 0 && first_pad[b] == INT_MAX) first_pad[b] = t + 1;
+            }
+        }
+        p0 = first_pad[b];
+        running = !done[b];          // a finished row's later tokens are discarded: no need to keep it exact
+        if (x_next) {
+            rowmap_next[b] = b * max_len + t + 1;
+            if (p0 != INT_MAX && running && t + 1 > p0) base = atomicAdd(nrows_next, t + 1 - p0) - B;
+        }
+    }
+    if (!x_next) return;
+    p0 = __shfl(p0, 0, 64);
+    running = __shfl(running, 0, 64);
+    base = __shfl(base, 0, 64);
+    const int nv = E / 4;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(emb + (int64_t)i * E);
+        const f32x4* pp = reinterpret_cast<const f32x4*>(pe + (int64_t)(t + 1) * E);
+        f32x4* dst = reinterpret_cast<f32x4*>(x_next + (int64_t)b * E);
+        for (int c = lane; c < nv; c += 64) dst[c] = src[c] + pp[c];
+    }
+    if (p0 == INT_MAX || !running || t + 1 <= p0) return;
+    const int cnt = t + 1 - p0;      // positions p0 .. t are re-run at step t+1
+    if (base + cnt > extra_cap && lane == 0 && dirty) dirty[b] = 1;   // list full: the host re-decodes this row exactly
+    for (int k = 0; k < cnt; ++k) {
+        const int slot = base + k;
+        if (slot >= extra_cap) break;
+        const int p = p0 + k;
+        if (lane == 0) rowmap_next[B + slot] = b * max_len + p;
+        const int id = tok[(int64_t)b * ldtok + p];
+        const f32x4* src = reinterpret_cast<const f32x4*>(emb + (int64_t)id * E);
+        const f32x4* pp = reinterpret_cast<const f32x4*>(pe + (int64_t)p * E);
+        f32x4* dst = reinterpret_cast<f32x4*>(x_next + (int64_t)(B + slot) * E);
+        for (int c = lane; c < nv; c += 64) dst[c] = src[c] + pp[c];
+    }
+}
+
+size_t capdec_tf_decode_workspace_bytes(const capdec_tf_model* m, int B, int S, int max_len, int extra_cap) {
+    if (check_model(m) != 0 || B < 0 || S < 1 || max_len < 1 || extra_cap < 0) return 0;
+    return carve_decode(m, B, S, max_len, extra_cap ? extra_cap : default_extra_cap(B), nullptr, nullptr);
 }
 
 int capdec_event_create(void** ev) {
@@ -218,25 +314,38 @@ int capdec_event_elapsed_ms(void* begin, void* end, float* ms) {
     return (int)hipEventElapsedTime(ms, (hipEvent_t)begin, (hipEvent_t)end);
 }
 
+// y = x W^T + b (+ R) over the first rows_dev[0] rows of an Mcap-row slab
+static int linear_rows(const float* x, int Mcap, const float* W, const float* b, int E, float* C, const float* R,
+                       int flags, const int32_t* rows_dev, hipStream_t s) {
+    capdec_gemm_group g = linear_group(x, E, Mcap, W, b, E, C, E, R, E);
+    g.ldq = E;
+    capdec_gemm_extra ex{};
+    ex.rows_dev = rows_dev;
+    return capdec_launch_gemm(&g, 1, E, flags, s, &ex);
+}
+
 int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, int S, int max_len, int sos, int eos,
-                            int flags, void* workspace, size_t workspace_bytes, int64_t* out_ids, int32_t* out_len,
-                            int32_t* out_dirty, const capdec_probe* probe, void* stream) {
+                            int flags, int extra_cap, void* workspace, size_t workspace_bytes, int64_t* out_ids,
+                            int32_t* out_len, int32_t* out_dirty, const capdec_probe* probe, void* stream) {
     CAPDEC_TRY(check_model(m));
-    CAPDEC_REQUIRE(enc && out_ids && out_len && B >= 0 && S >= 1 && S <= 2048 && max_len >= 1);
+    CAPDEC_REQUIRE(enc && out_ids && out_len && out_dirty && B >= 0 && S >= 1 && S <= 2048 && max_len >= 1);
     CAPDEC_REQUIRE(max_len <= m->max_pos);           // the reference's pe buffer has max_pos rows
-    CAPDEC_REQUIRE(sos >= 0 && sos < m->V);
+    CAPDEC_REQUIRE(sos >= 0 && sos < m->V && extra_cap >= 0);
+    CAPDEC_REQUIRE((int64_t)B * max_len < INT_MAX);
     if (B == 0) return 0;
     if (!workspace || !capdec_aligned16(workspace) || !capdec_aligned16(enc)) return CAPDEC_EALIGN;
+    if (extra_cap == 0) extra_cap = default_extra_cap(B);
     DecodeWs w;
-    if (carve_decode(m, B, S, max_len, workspace, &w) > workspace_bytes) return CAPDEC_ENOMEM;
+    if (carve_decode(m, B, S, max_len, extra_cap, workspace, &w) > workspace_bytes) return CAPDEC_ENOMEM;
     hipStream_t s = (hipStream_t)stream;
     const int E = m->E, H = m->H, dk = E / H, L = m->L, V = m->V;
+    const int Mcap = B + extra_cap;
     const int64_t ldtok = max_len + 1;
     const size_t BE = (size_t)B * E;
     const bool s1 = (S == 1) && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT);
 
-    hipLaunchKernelGGL(greedy_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, out_ids, out_len,
-                       out_dirty, B, max_len, sos);
+    hipLaunchKernelGGL(cached_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, w.first_pad, out_ids,
+                       out_len, out_dirty, w.rowmap, w.nrows, B, max_len, sos);
     CAPDEC_LAUNCH_CHECK();
     CAPDEC_TRY(capdec_embed_pe(w.tok, 1, ldtok, m->emb, m->pe, 0, B, 1, E, V, w.x, stream));
 
@@ -254,47 +363,54 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
 
     const int nt = capdec_vocab_tiles(V);
     for (int t = 0; t < max_len; ++t) {
+        const int32_t* rows = w.nrows + t;                       // device: B + re-run rows of this step
+        const int32_t* map = w.rowmap + (size_t)t * Mcap;        // device: sample * max_len + position per row
         for (int l = 0; l < L; ++l) {
             const capdec_tf_layer& ly = m->layers[l];
             float* kc = w.kc + (size_t)l * BE * max_len;
             float* vc = w.vc + (size_t)l * BE * max_len;
-            // q, and this position's k/v straight into the cache rows
+            // q, and every row's k/v straight into its cache row
             capdec_gemm_group g[3];
-            g[0] = linear_group(w.x, E, B, ly.self_attn.wq, ly.self_attn.bq, E, w.q, E);
-            g[1] = linear_group(w.x, E, B, ly.self_attn.wk, ly.self_attn.bk, E, kc + (size_t)t * E, (int64_t)max_len * E);
-            g[2] = linear_group(w.x, E, B, ly.self_attn.wv, ly.self_attn.bv, E, vc + (size_t)t * E, (int64_t)max_len * E);
+            g[0] = linear_group(w.x, E, Mcap, ly.self_attn.wq, ly.self_attn.bq, E, w.q, E);
+            g[1] = linear_group(w.x, E, Mcap, ly.self_attn.wk, ly.self_attn.bk, E, kc, E);
+            g[2] = linear_group(w.x, E, Mcap, ly.self_attn.wv, ly.self_attn.bv, E, vc, E);
             g[0].ldq = g[1].ldq = g[2].ldq = E;
-            CAPDEC_TRY(capdec_launch_gemm(g, 3, E, 0, s));
-            CAPDEC_TRY(capdec_attention(w.q, E, kc, E, (int64_t)max_len * E, vc, E, (int64_t)max_len * E, w.ao, E, B, H,
-                                        1, t + 1, dk, 0, 0, w.tok + t, ldtok, nullptr, stream));
-            CAPDEC_TRY(linear(w.ao, E, B, ly.self_attn.wo, ly.self_attn.bo, E, E, w.y, E, w.x, E, 0, s));
-            CAPDEC_TRY(capdec_add_layernorm(w.y, nullptr, 1, ly.n1_g, ly.n1_b, 1e-5f, B, E, w.x1, nullptr, nullptr,
-                                            stream));
+            g[1].c_rows = g[2].c_rows = map;
+            capdec_gemm_extra ex{};
+            ex.rows_dev = rows;
+            CAPDEC_TRY(capdec_launch_gemm(g, 3, E, 0, s, &ex));
+            CAPDEC_TRY(capdec_launch_attention_rows(w.q, E, kc, E, (int64_t)max_len * E, vc, E, (int64_t)max_len * E,
+                                                    w.ao, E, Mcap, H, t + 1, dk, 1, w.tok, ldtok, map, max_len, rows, s));
+            CAPDEC_TRY(linear_rows(w.ao, Mcap, ly.self_attn.wo, ly.self_attn.bo, E, w.y, w.x, 0, rows, s));
+            CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, Mcap, E, w.x1,
+                                                    rows, s));
             if (s1) {
-                CAPDEC_TRY(capdec_add_layernorm(w.x1, w.cc + l * BE, 1, ly.n2_g, ly.n2_b, 1e-5f, B, E, w.x2, nullptr,
-                                                nullptr, stream));
+                CAPDEC_TRY(capdec_launch_layernorm_rows(w.x1, w.cc + l * BE, max_len, map, ly.n2_g, ly.n2_b, 1e-5f,
+                                                        Mcap, E, w.x2, rows, s));
             } else {
-                CAPDEC_TRY(linear(w.x1, E, B, ly.cross_attn.wq, ly.cross_attn.bq, E, E, w.q, E, nullptr, 0, 0, s));
-                CAPDEC_TRY(capdec_attention(w.q, E, w.ck + (size_t)l * BE * S, E, (int64_t)S * E,
-                                            w.cv + (size_t)l * BE * S, E, (int64_t)S * E, w.ao, E, B, H, 1, S, dk, 0, 0,
-                                            nullptr, 0, nullptr, stream));
-                CAPDEC_TRY(linear(w.ao, E, B, ly.cross_attn.wo, ly.cross_attn.bo, E, E, w.y, E, w.x1, E, 0, s));
-                CAPDEC_TRY(capdec_add_layernorm(w.y, nullptr, 1, ly.n2_g, ly.n2_b, 1e-5f, B, E, w.x2, nullptr, nullptr,
-                                                stream));
+                CAPDEC_TRY(linear_rows(w.x1, Mcap, ly.cross_attn.wq, ly.cross_attn.bq, E, w.q, nullptr, 0, rows, s));
+                CAPDEC_TRY(capdec_launch_attention_rows(w.q, E, w.ck + (size_t)l * BE * S, E, (int64_t)S * E,
+                                                        w.cv + (size_t)l * BE * S, E, (int64_t)S * E, w.ao, E, Mcap, H, S,
+                                                        dk, 0, nullptr, 0, map, max_len, rows, s));
+                CAPDEC_TRY(linear_rows(w.ao, Mcap, ly.cross_attn.wo, ly.cross_attn.bo, E, w.y, w.x1, 0, rows, s));
+                CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n2_g, ly.n2_b, 1e-5f, Mcap, E,
+                                                        w.x2, rows, s));
             }
-            CAPDEC_TRY(linear(w.x2, E, B, ly.ff_w1, ly.ff_b1, E, E, w.hb, E, nullptr, 0, CAPDEC_GEMM_RELU, s));
-            CAPDEC_TRY(linear(w.hb, E, B, ly.ff_w2, ly.ff_b2, E, E, w.y, E, w.x2, E, 0, s));
-            CAPDEC_TRY(capdec_add_layernorm(w.y, nullptr, 1, ly.n3_g, ly.n3_b, 1e-5f, B, E, w.x, nullptr, nullptr,
-                                            stream));
+            CAPDEC_TRY(linear_rows(w.x2, Mcap, ly.ff_w1, ly.ff_b1, E, w.hb, nullptr, CAPDEC_GEMM_RELU, rows, s));
+            CAPDEC_TRY(linear_rows(w.hb, Mcap, ly.ff_w2, ly.ff_b2, E, w.y, w.x2, 0, rows, s));
+            CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n3_g, ly.n3_b, 1e-5f, Mcap, E, w.x,
+                                                    rows, s));
         }
+        // only the B new rows predict a token
         const bool probed = probe && t < probe->n;
         if (probed) CAPDEC_TRY((int)hipEventRecord((hipEvent_t)probe->begin[t], s));
         CAPDEC_TRY(capdec_vocab_argmax_partial(w.x, E, m->fc2_w, m->fc2_b, B, V, E, w.pval, w.pidx, stream));
         if (probed) CAPDEC_TRY((int)hipEventRecord((hipEvent_t)probe->end[t], s));
         const bool last = (t + 1 == max_len);
-        hipLaunchKernelGGL(greedy_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
-                           eos, w.tok, ldtok, w.done, out_ids, out_len, out_dirty, m->emb, m->pe, E, V,
-                           last ? nullptr : w.x);
+        hipLaunchKernelGGL(cached_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
+                           eos, w.tok, ldtok, w.done, w.first_pad, out_ids, out_len, out_dirty, m->emb, m->pe, E, V,
+                           last ? nullptr : w.x, last ? nullptr : w.rowmap + (size_t)(t + 1) * Mcap,
+                           last ? nullptr : w.nrows + t + 1, extra_cap);
         CAPDEC_LAUNCH_CHECK();
     }
     return 0;

@@ -252,12 +252,14 @@ __global__ __launch_bounds__(128 * WM * KG) void gemm_kernel(GemmKArgs args) {
     const capdec_gemm_group& g = args.g[grp];
     constexpr int BI = 32 * WM * WI, BJ = 64 * WJ;
     const int i0 = blockIdx.y * BI, j0 = blockIdx.x * BJ;
-    if (i0 >= g.I || j0 >= g.J) return;   // groups of different size share the grid
+    // rows_dev: the number of live rows is only known on the device (decode steps that re-run a few rows)
+    const int nI = args.x.rows_dev ? min(g.I, args.x.rows_dev[0]) : g.I;
+    if (i0 >= nI || j0 >= g.J) return;   // groups of different size share the grid
     const int nk = (args.K + BK - 1) / BK;
     const int per = (nk + args.nsplit - 1) / args.nsplit;
     const int kt0 = split * per, kt1 = min(nk, kt0 + per);
     f32x16 acc[WI][WJ];
-    mainloop<WM, WI, WJ, BK, VEC, TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, g.I, g.J, args.K, i0, j0, kt0, kt1, lds, acc);
+    mainloop<WM, WI, WJ, BK, VEC, TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, nI, g.J, args.K, i0, j0, kt0, kt1, lds, acc);
     if (KG > 1 && threadIdx.x >= 128 * WM) return;   // group 0 holds the summed tile
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -277,8 +279,10 @@ __global__ __launch_bounds__(128 * WM * KG) void gemm_kernel(GemmKArgs args) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = i0 + wi * 32 * WI + ti * 32 + acc_row(e, h);
-                if (i >= g.I) continue;
-                float* c = &g.C[(int64_t)i * g.ldci + (int64_t)j * g.ldcj];
+                if (i >= nI) continue;
+                // c_rows: output row i is stored at row c_rows[i] (k/v of a decode step go straight to their cache rows)
+                const int64_t ci = g.c_rows ? (int64_t)g.c_rows[i] : (int64_t)i;
+                float* c = &g.C[ci * g.ldci + (int64_t)j * g.ldcj];
                 if (atomic) {
                     // C += partial; the affine terms (bias, BatchNorm shift) enter once, with the first k-range
                     float v = acc[ti][tj][e];

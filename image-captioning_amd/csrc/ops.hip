@@ -35,13 +35,17 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
                                                             int add_div, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, int M, int E,
                                                             float* __restrict__ y, float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out) {
+                                                            float* __restrict__ rstd_out,
+                                                            const int32_t* __restrict__ add_map,
+                                                            const int32_t* __restrict__ rows_dev) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= M) return;
+    if (row >= M || (rows_dev && row >= rows_dev[0])) return;
     const int nv = E / 4;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * E);
-    const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (int64_t)(row / add_div) * E) : nullptr;
+    // the addend's row: row / add_div, or (add_map[row] / add_div) when rows are listed explicitly
+    const int arow = (add_map ? add_map[row] : row) / add_div;
+    const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (int64_t)arow * E) : nullptr;
     f32x4 v[LN_MAXV];
     float s = 0.f;
 #pragma unroll
@@ -90,6 +94,9 @@ struct AttnArgs {
     int causal, causal_off;
     const int32_t* ids; int64_t ldid;
     float* lse;
+    // row-list form (decode steps): Tq == 1, query/output row r, sample and position from row_map[r]
+    const int32_t* row_map; int map_div;     // b = row_map[r] / map_div, position = row_map[r] % map_div
+    const int32_t* rows_dev;                 // nullable device scalar: only rows r < rows_dev[0] are live
 };
 
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
@@ -97,11 +104,20 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long total = (long)a.B * a.H * a.Tq;
     long idx = (long)blockIdx.x * 4 + wave;
-    const bool live = idx < total;
+    bool live = idx < total;
     if (!live) idx = total - 1;            // keep the wave in the barriers; it stores nothing
-    const int i = (int)(idx % a.Tq);
+    int i = (int)(idx % a.Tq);             // position of the query inside its sample (mask / causal limit)
     const int h = (int)((idx / a.Tq) % a.H);
-    const int b = (int)(idx / ((long)a.Tq * a.H));
+    int b = (int)(idx / ((long)a.Tq * a.H));
+    int64_t qrow = (int64_t)b * a.Tq + i;  // row of q / out
+    if (a.row_map) {
+        const int r = (int)(idx / a.H);
+        if (a.rows_dev && r >= a.rows_dev[0]) live = false;
+        const int m = a.row_map[live ? r : 0];
+        b = m / a.map_div;
+        i = m - b * a.map_div;
+        qrow = r;
+    }
     float* sc = lds + wave * a.Tk;         // this wave's score row
 
     const bool pad_row = a.ids && a.ids[(int64_t)b * a.ldid + i] == 0;
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     if (!pad_row) {
         // scores: 4 lanes per key, each lane owns dims {4*part + 16*m}
         const int part = lane & 3, kl = lane >> 2;
-        const float* qp = a.q + ((int64_t)b * a.Tq + i) * a.ldq + (int64_t)h * dk + 4 * part;
+        const float* qp = a.q + qrow * a.ldq + (int64_t)h * dk + 4 * part;
         const int nm = dk / 16;
         f32x4 qreg[16];
 #pragma unroll
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         acc[3] += __shfl_xor(acc[3], o, 64);
     }
     if (live && grp == 0)
-        *reinterpret_cast<f32x4*>(a.out + ((int64_t)b * a.Tq + i) * a.ldo + (int64_t)h * dk + 4 * dl) = acc;
+        *reinterpret_cast<f32x4*>(a.out + qrow * a.ldo + (int64_t)h * dk + 4 * dl) = acc;
     if (live && lane == 0 && a.lse) a.lse[idx] = mx + logf(sum);
 }
 
@@ -239,6 +255,30 @@ __global__ __launch_bounds__(256) void bn_train_kernel(const float* __restrict__
 
 }  // namespace
 
+// ---- row-list forms used by the decode engine (device-side row count, explicit (sample, position) per row) ----
+int capdec_launch_layernorm_rows(const float* x, const float* add, int add_div, const int32_t* add_map,
+                                 const float* gamma, const float* beta, float eps, int Mcap, int E, float* y,
+                                 const int32_t* rows_dev, hipStream_t s) {
+    if (Mcap == 0) return 0;
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3((Mcap + 3) / 4), dim3(256), 0, s, x, add, add ? add_div : 1, gamma,
+                       beta, eps, Mcap, E, y, (float*)nullptr, (float*)nullptr, add_map, rows_dev);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_launch_attention_rows(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
+                                 int64_t ldv, int64_t sv, float* out, int64_t ldo, int Rcap, int H, int Tk, int dk,
+                                 int causal, const int32_t* ids, int64_t ldid, const int32_t* row_map, int map_div,
+                                 const int32_t* rows_dev, hipStream_t s) {
+    if (Rcap == 0) return 0;
+    AttnArgs a{q, ldq, k, ldk, sk, v, ldv, sv, out, ldo, Rcap, H, 1, Tk, dk, causal, 0, ids, ldid, nullptr,
+               row_map, map_div, rows_dev};
+    const long total = (long)Rcap * H;
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 4 * Tk * sizeof(float), s, a);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" {
 
 int capdec_abi_version(void) { return CAPDEC_ABI_VERSION; }
@@ -279,7 +319,8 @@ int capdec_add_layernorm(const float* x, const float* add, int add_div, const fl
         return CAPDEC_EALIGN;
     if (M == 0) return 0;
     hipLaunchKernelGGL(add_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add,
-                       add ? add_div : 1, gamma, beta, eps, M, E, y, mean, rstd);
+                       add ? add_div : 1, gamma, beta, eps, M, E, y, mean, rstd, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -294,7 +335,8 @@ int capdec_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, i
         ldk % 4 || sk % 4 || ldv % 4 || sv % 4 || ldo % 4)
         return CAPDEC_EALIGN;
     if (B == 0) return 0;
-    AttnArgs a{q, ldq, k, ldk, sk, v, ldv, sv, out, ldo, B, H, Tq, Tk, dk, causal, causal_off, ids, ldid, lse};
+    AttnArgs a{q, ldq, k, ldk, sk, v, ldv, sv, out, ldo, B, H, Tq, Tk, dk, causal, causal_off, ids, ldid, lse,
+               nullptr, 1, nullptr};
     const long total = (long)B * H * Tq;
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 4 * Tk * sizeof(float),
                        (hipStream_t)stream, a);

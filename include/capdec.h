@@ -54,6 +54,7 @@ typedef struct capdec_gemm_group {
     const float* R;        /* nullable residual */
     int64_t ldp, ldq, ldci, ldcj, ldri, ldrj;
     int32_t I, J;
+    const int32_t* c_rows; /* nullable, device [I]: output row i is stored at row c_rows[i] of C (scatter) */
 } capdec_gemm_group;
 
 #define CAPDEC_GEMM_RELU 1
@@ -78,6 +79,7 @@ int capdec_gemm(const capdec_gemm_group* groups /*host*/, int ngroups, int K, in
 typedef struct capdec_gemm_extra {
     const float* mask; int64_t ldm;
     const float* lse; const int64_t* tgt; const float* gscale; int64_t ignore_index;
+    const int32_t* rows_dev;   /* nullable device scalar: only rows i < min(I, rows_dev[0]) are computed */
 } capdec_gemm_extra;
 /* Tuning hook for benchmarks: 0 = automatic tile choice, 11 = 64x64 (BK 32), 22 = 128x128 (BK 32), 216 = 128x128 (BK 16),
  * 32 = 32x64 tile with its k-loop split over the two wave pairs.  Process-wide; not for production use. */
@@ -219,15 +221,18 @@ typedef struct capdec_tf_model {
 } capdec_tf_model;
 
 /* bytes of caller-provided device workspace for the calls below */
-size_t capdec_tf_decode_workspace_bytes(const capdec_tf_model* m, int B, int S, int max_len);
+size_t capdec_tf_decode_workspace_bytes(const capdec_tf_model* m, int B, int S, int max_len, int extra_cap);
 
 /* KV-cached greedy decode.  enc [B,S,E].  out_ids [B,max_len] int64: every predicted id before the
- * row's first <eos>, then -1.  out_len [B].  out_dirty [B]: 1 where the row predicted id 0 (<PAD>) before
- * finishing -- such a row's later tokens need capdec_tf_greedy_decode_exact, because the reference masks a
- * PAD query row to a uniform softmax over the *current* length, which no cache can hold.  All max_len steps
- * are always enqueued (there is no host sync to test the reference's all-rows-done early exit, which has no
- * visible effect on the outputs).  With S == 1 the softmax over the single memory row is exactly 1, so the
- * cross-attention block reduces to one vector per sample and layer that is computed once (bit-identical). */
+ * row's first <eos>, then -1.  out_len [B].
+ * Generated <PAD> tokens: the reference masks a PAD *query row*, which then attends uniformly over the CURRENT
+ * length, so every position from a sample's first PAD on changes at each later step.  Those positions are re-run
+ * inside the step (through the same kernels, k/v rewritten in the cache) as extra rows after the B new ones; at
+ * most extra_cap of them per step (0 = default max(64, B/4)).  out_dirty [B] is set to 1 for a sample whose
+ * re-run rows did not fit: only such samples need capdec_tf_greedy_decode_exact afterwards.
+ * All max_len steps are always enqueued (there is no host sync to test the reference's all-rows-done early exit,
+ * which has no visible effect on the outputs).  With S == 1 the softmax over the single memory row is exactly 1,
+ * so the cross-attention block reduces to one vector per sample and layer that is computed once. */
 /* Optional timing probe: HIP events recorded on `stream` right before / after the vocabulary-projection
  * kernel of decode step t, for t < n.  Events are created with capdec_event_create; read them with
  * capdec_event_elapsed_ms after the stream has been synchronised.  Measurement plumbing only: it has no
@@ -244,8 +249,8 @@ int capdec_event_elapsed_ms(void* begin, void* end, float* ms);
 
 #define CAPDEC_DECODE_NO_S1_SHORTCUT 1   /* run the general cross-attention kernels even when S == 1 */
 int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, int S, int max_len, int sos, int eos,
-                            int flags, void* workspace, size_t workspace_bytes, int64_t* out_ids, int32_t* out_len,
-                            int32_t* out_dirty, const capdec_probe* probe /*nullable*/, void* stream);
+                            int flags, int extra_cap, void* workspace, size_t workspace_bytes, int64_t* out_ids,
+                            int32_t* out_len, int32_t* out_dirty, const capdec_probe* probe /*nullable*/, void* stream);
 
 /* Exact full-prefix greedy decode (re-runs the whole prefix every step, as the reference does).
  * Same outputs; used for rows flagged dirty above and as an in-library cross-check. */

@@ -253,16 +253,24 @@ def test_f5_greedy_random_weights_cached_and_exact():
             check_greedy(got, sd, enc, int(fx["H"]), 12, want_rows=want)
 
 
-def test_f5_greedy_generated_pad_rows_take_the_exact_path():
+def test_f5_greedy_generated_pad_rows_are_rerun_inside_the_cached_loop():
+    """Weights crafted so that most rows emit <PAD> mid-sequence: the cached decoder must reproduce the reference
+    (which masks the PAD query row to a uniform softmax over the CURRENT length) without the host fallback when
+    the per-step row list is large enough, and through the exact fallback when it is not."""
     fx = load_golden("f5_greedy")
     sd = sub_sd(fx, "b__sd__")
     dec = decoder_from_sd(sd, int(fx["H"]))
     enc = t(fx["b_enc"])
     want = unpad(fx["b_ids"])
-    got, n_dirty = _greedy(dec, enc, 14)
-    assert n_dirty > 0
+    got, n_fallback = _greedy(dec, enc, 14, extra_cap=256)
+    assert n_fallback == 0
     assert check_greedy(got, sd, enc, int(fx["H"]), 14, want_rows=want) == 0
     assert got == want
+    got, n_fallback = _greedy(dec, enc, 14, extra_cap=8)          # list overflows -> exact re-decode of those samples
+    assert n_fallback > 0
+    assert got == want
+    got, _ = _greedy(dec, enc, 14, extra_cap=8, resolve_dirty=False)
+    assert got != want                                            # without the fallback the overflowed samples are wrong
 
 
 def test_f5_greedy_rows_finish_early():

@@ -41,7 +41,7 @@ def test_argument_validation_without_gpu():
     assert lib.capdec_add_layernorm(None, None, 1, None, None, 1e-5, 4, 64, None, None, None, None) == -22
     assert lib.capdec_attention(None, 0, None, 0, 0, None, 0, 0, None, 0, 1, 1, 1, 1, 64, 0, 0, None, 0, None, None) == -22
     m = _lib.TfModel(E=10, H=3, L=1, V=5, max_pos=4)
-    assert lib.capdec_tf_decode_workspace_bytes(m, 4, 1, 4) == 0       # E % H != 0
+    assert lib.capdec_tf_decode_workspace_bytes(m, 4, 1, 4, 0) == 0       # E % H != 0
 
 
 def test_state_dict_keys_match_reference():
