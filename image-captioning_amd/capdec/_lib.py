@@ -69,12 +69,14 @@ _SIGNATURES = {
     "capdec_attention": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P]),
     "capdec_lstm_step": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P, _P]),
+    "capdec_lstm_step_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, _P, _P, _P]),
     "capdec_gemm_force_config": (c_int, [c_int]),
     "capdec_gemm_ex": (c_int, [POINTER(GemmGroup), c_int, c_int, c_int, POINTER(GemmExtra), _P]),
     "capdec_dropout": (c_int, [_P, c_int64, c_float, c_uint64, _P, _P]),
-    "capdec_add_layernorm_train": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
+    "capdec_add_layernorm_train": (c_int, [_P, c_int, _P, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
     "capdec_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
     "capdec_colsum": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
+    "capdec_group_sum": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "capdec_embed_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "capdec_bn_train_backward": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "capdec_attention_bwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, _P,

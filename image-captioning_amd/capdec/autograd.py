@@ -44,7 +44,7 @@ def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None):
 # ---------------------------------------------------------------------------------------------
 # Transformer decoder stack
 # ---------------------------------------------------------------------------------------------
-def tf_forward(dec, enc, ids, p, seed):
+def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True):
     """Teacher-forced decoder stack (reference transformer.py:125-132) keeping what the backward needs.
     enc [B,S,E] fp32, ids [B,T] int64.  Returns (x [B*T,E] post-LN output of the last layer, tape)."""
     B, S, E = enc.shape
@@ -52,6 +52,7 @@ def tf_forward(dec, enc, ids, p, seed):
     M, H = B * T, dec.num_heads
     t = Tape()
     t.B, t.S, t.T, t.E, t.H, t.p, t.seed = B, S, T, E, H, p, seed
+    t.shortcut = S == 1 and single_row_shortcut
     t.ids = ids.contiguous()
     t.ids32 = t.ids.to(torch.int32)
     t.enc = enc.reshape(B * S, E)
@@ -75,14 +76,22 @@ def tf_forward(dec, enc, ids, p, seed):
         c.ao, c.lse = ops.attention(qkv[0], qkv[1], qkv[2], B, H, T, T, causal=True, ids32=t.ids32, want_lse=True)
         a = ops.linear(c.ao, sa.W_o.weight, sa.W_o.bias)
         c.x1, c.s1, c.m1, c.r1 = ops.add_layernorm_train(a, x, ly.norm1.weight, ly.norm1.bias, p, sd)
-        c.q2 = ops.linear(c.x1, ca.W_q.weight, ca.W_q.bias)
-        kv2 = torch.empty((2, B * S, E), device=x.device, dtype=torch.float32)
-        ops.gemm_groups([dict(P=t.enc, Q=ca.W_k.weight, C=kv2[0], bias_j=ca.W_k.bias),
-                         dict(P=t.enc, Q=ca.W_v.weight, C=kv2[1], bias_j=ca.W_v.bias)], E)
-        c.kv2 = kv2
-        c.ao2, c.lse2 = ops.attention(c.q2, kv2[0], kv2[1], B, H, T, S, want_lse=True)
-        a2 = ops.linear(c.ao2, ca.W_o.weight, ca.W_o.bias)
-        c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(a2, c.x1, ly.norm2.weight, ly.norm2.bias, p, sd + _SITE)
+        if S == 1 and single_row_shortcut:
+            # one memory row: the softmax over it is exactly 1, so the sub-layer output is W_o(W_v enc + b_v) + b_o
+            # for every position, whatever the query (reference transformer.py:13-22 with Tk = 1)
+            c.v2 = ops.linear(t.enc, ca.W_v.weight, ca.W_v.bias)                       # [B,E]
+            c.cc = ops.linear(c.v2, ca.W_o.weight, ca.W_o.bias)                        # [B,E]
+            c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(c.cc, c.x1, ly.norm2.weight, ly.norm2.bias, p,
+                                                             sd + _SITE, x_div=T)
+        else:
+            c.q2 = ops.linear(c.x1, ca.W_q.weight, ca.W_q.bias)
+            kv2 = torch.empty((2, B * S, E), device=x.device, dtype=torch.float32)
+            ops.gemm_groups([dict(P=t.enc, Q=ca.W_k.weight, C=kv2[0], bias_j=ca.W_k.bias),
+                             dict(P=t.enc, Q=ca.W_v.weight, C=kv2[1], bias_j=ca.W_v.bias)], E)
+            c.kv2 = kv2
+            c.ao2, c.lse2 = ops.attention(c.q2, kv2[0], kv2[1], B, H, T, S, want_lse=True)
+            a2 = ops.linear(c.ao2, ca.W_o.weight, ca.W_o.bias)
+            c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(a2, c.x1, ly.norm2.weight, ly.norm2.bias, p, sd + _SITE)
         c.h = ops.linear(c.x2, ff.fc1.weight, ff.fc1.bias, relu=True)
         f = ops.linear(c.h, ff.fc2.weight, ff.fc2.bias)
         x, c.s3, c.m3, c.r3 = ops.add_layernorm_train(f, c.x2, ly.norm3.weight, ly.norm3.bias, p, sd + 2 * _SITE)
@@ -111,11 +120,19 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         d_x1, d_a2 = ops.layernorm_bwd(d_x2, c.s2, c.m2, c.r2, ly.norm2.weight, p, sd + _SITE,
                                        _new(grads, pre + "norm2.weight", ly.norm2.weight),
                                        _new(grads, pre + "norm2.bias", ly.norm2.bias))
-        d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2)
-        dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S)
-        _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1)
-        _lin_bwd(grads, pre + "cross_attn.W_k", ca.W_k, dk2, t.enc, need_dx=need_denc, accum=denc)
-        _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, dv2, t.enc, need_dx=need_denc, accum=denc)
+        if t.shortcut:
+            d_cc = ops.group_sum(d_a2, T)                                              # [B,E]
+            d_v2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_cc, c.v2)
+            _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, d_v2, t.enc, need_dx=need_denc, accum=denc)
+            for n, prm in (("W_q.weight", ca.W_q.weight), ("W_q.bias", ca.W_q.bias), ("W_k.weight", ca.W_k.weight),
+                           ("W_k.bias", ca.W_k.bias)):
+                _new(grads, pre + "cross_attn." + n, prm)                              # exactly zero
+        else:
+            d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2)
+            dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S)
+            _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1)
+            _lin_bwd(grads, pre + "cross_attn.W_k", ca.W_k, dk2, t.enc, need_dx=need_denc, accum=denc)
+            _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, dv2, t.enc, need_dx=need_denc, accum=denc)
         # x1 = LN1(x + drop(a)),  a = attn(x Wq, x Wk, x Wv; causal, PAD rows) Wo
         d_x, d_a = ops.layernorm_bwd(d_x1, c.s1, c.m1, c.r1, ly.norm1.weight, p, sd,
                                      _new(grads, pre + "norm1.weight", ly.norm1.weight),
@@ -275,5 +292,105 @@ def head_train(model, parts, x, dropout_first):
     return _HeadFn.apply(model, parts, names, dropout_first, x, *params)
 
 
+# ---------------------------------------------------------------------------------------------
+# CNN-RNN: image step + teacher-forced LSTM (reference cnnrnn_model.py:20-34)
+# ---------------------------------------------------------------------------------------------
+def _lstm_w(rnn):
+    return (rnn.lstm.weight_ih_l0, rnn.lstm.weight_hh_l0, rnn.lstm.bias_ih_l0, rnn.lstm.bias_hh_l0)
+
+
+def rnn_forward(rnn, x0, ids, p, seed):
+    """LSTM over [image projection x0, dropout(embed(ids))] from the zero state, keeping what the backward
+    needs.  Everything is stored time-major (row = step * B + sample) so that every step is a contiguous
+    [B, .] block and the weight gradients are single contractions over all steps.
+    Returns (h [T*B, Hd] time-major outputs of the caption steps, tape)."""
+    B, T = ids.shape
+    E = x0.shape[1]
+    w_ih, w_hh, b_ih, b_hh = _lstm_w(rnn)
+    Hd = w_hh.shape[1]
+    dev = x0.device
+    t = Tape()
+    t.B, t.T, t.E, t.Hd, t.p, t.seed = B, T, E, Hd, p, seed
+    t.ids_tm = ids.t().contiguous()                                   # [T,B]
+    n = (T + 1) * B
+    t.x = torch.empty((n, E), device=dev, dtype=torch.float32)
+    t.h = torch.empty((n, Hd), device=dev, dtype=torch.float32)
+    t.c = torch.empty((n, Hd), device=dev, dtype=torch.float32)
+    t.g = torch.empty((n, 4 * Hd), device=dev, dtype=torch.float32)
+    t.x[:B].copy_(x0)
+    if T > 0:
+        if p > 0:
+            ops.dropout(ops.embed_pe(t.ids_tm, rnn.embed.weight, None), p, seed, out=t.x[B:])
+        else:
+            ops.embed_pe(t.ids_tm, rnn.embed.weight, None, out=t.x[B:])
+    lib_step = ops.lstm_step_into
+    lib_step(t.x[:B], None, None, w_ih, w_hh, b_ih, b_hh, t.h[:B], t.c[:B], t.g[:B])
+    for s in range(1, T + 1):
+        a, b, c = (s - 1) * B, s * B, (s + 1) * B
+        lib_step(t.x[b:c], t.h[a:b], t.c[a:b], w_ih, w_hh, b_ih, b_hh, t.h[b:c], t.c[b:c], t.g[b:c])
+    return t.h[B:], t
+
+
+def rnn_backward(rnn, t, dh_out, grads):
+    """Backward of ``rnn_forward``: dh_out [T*B, Hd] time-major.  Fills the lstm.* and embed.weight gradients;
+    returns d(x0) [B,E]."""
+    B, T, E, Hd = t.B, t.T, t.E, t.Hd
+    w_ih, w_hh, b_ih, b_hh = _lstm_w(rnn)
+    dg = torch.empty_like(t.g)
+    dh_rec, dc = None, None
+    for s in range(T, -1, -1):
+        a, b, c = (s - 1) * B, s * B, (s + 1) * B
+        dc = ops.lstm_step_bwd(t.g[b:c], t.c[a:b] if s > 0 else None, t.c[b:c],
+                               dh_out[a:b] if s > 0 else None, dh_rec, dc, dg[b:c])
+        if s > 0:
+            dh_rec = ops.linear_dgrad(dg[b:c], w_hh)
+    ops.linear_wgrad(dg, t.x, out=_new(grads, "lstm.weight_ih_l0", w_ih))
+    if T > 0:
+        ops.linear_wgrad(dg[B:], t.h[:T * B], out=_new(grads, "lstm.weight_hh_l0", w_hh))
+    else:
+        _new(grads, "lstm.weight_hh_l0", w_hh)
+    ops.colsum(dg, _new(grads, "lstm.bias_ih_l0", b_ih))
+    ops.colsum(dg, _new(grads, "lstm.bias_hh_l0", b_hh))
+    dx = ops.linear_dgrad(dg, w_ih)
+    if T > 0:
+        demb = dx[B:]
+        if t.p > 0:
+            demb = ops.dropout(demb, t.p, t.seed)
+        ops.embed_bwd(t.ids_tm.view(-1), demb, _new(grads, "embed.weight", rnn.embed.weight))
+    else:
+        _new(grads, "embed.weight", rnn.embed.weight)
+    return dx[:B]
+
+
+_RNN_PARAMS = ("embed.weight", "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0",
+               "fc2.weight", "fc2.bias")
+
+
+class _RnnLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rnn, captions, x0, *params):
+        p = rnn.dropout.p if rnn.training else 0.0
+        h, tape = rnn_forward(rnn, x0.detach().contiguous(), captions, p, draw_seed() if p > 0 else 0)
+        B, T = captions.shape
+        logits_tm = ops.linear(h, rnn.fc2.weight, rnn.fc2.bias)          # [T*B, V]
+        ctx.rnn, ctx.tape, ctx.h = rnn, tape, h
+        return logits_tm.view(T, B, -1).transpose(0, 1)                  # [B,T,V] view of the time-major rows
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        rnn, tape = ctx.rnn, ctx.tape
+        grads = {}
+        V = dlogits.shape[-1]
+        d_tm = dlogits.transpose(0, 1).contiguous().view(-1, V)          # back to time-major rows
+        dh = _lin_bwd(grads, "fc2", rnn.fc2, d_tm, ctx.h)
+        dx0 = rnn_backward(rnn, tape, dh, grads)
+        return (None, None, dx0) + tuple(grads.get(n) for n in _RNN_PARAMS)
+
+
 def decoder_rnn_forward(rnn, features, captions):
-    raise NotImplementedError("CNN-RNN training (LSTM backward) is not built yet; inference and greedy decode are")
+    """Autograd-connected ``DecoderRNN.forward`` (reference cnnrnn_model.py:20-34): logits [B,T,V]."""
+    if not features.is_cuda or not captions.is_cuda:
+        raise RuntimeError("capdec: inputs must live on the GPU (HIP); there is no CPU path")
+    x0 = rnn.image_input(features)                                       # head: autograd-connected in train mode
+    named = dict(rnn.named_parameters())
+    return _RnnLogitsFn.apply(rnn, captions, x0, *[named[n] for n in _RNN_PARAMS])

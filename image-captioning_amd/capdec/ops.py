@@ -80,7 +80,7 @@ def linear(x, W, b=None, relu=False, residual=None, scale=None, shift=None, out=
     return out
 
 
-def embed_pe(ids, emb, pe, pos0=0):
+def embed_pe(ids, emb, pe, pos0=0, out=None):
     """ids [B,T] int64/int32 -> [B*T, E] = emb[ids] + pe[pos0 : pos0+T]  (pe may be None)."""
     lib = _lib.load()
     if ids.dtype not in (torch.int64, torch.int32):
@@ -91,7 +91,9 @@ def embed_pe(ids, emb, pe, pos0=0):
     V, E = emb.shape
     if ids.stride(1) != 1 and T > 1:
         ids = ids.contiguous()
-    x = torch.empty((B * T, E), device=emb.device, dtype=torch.float32)
+    x = torch.empty((B * T, E), device=emb.device, dtype=torch.float32) if out is None else _chk(out, name="out")
+    if x.shape != (B * T, E) or not x.is_contiguous():
+        raise RuntimeError(f"capdec embed_pe: out must be a contiguous [{B * T},{E}] tensor")
     if pe is not None:
         _chk(pe, name="pe")
         if pe.dim() != 2 or pe.shape[1] != E or pe.shape[0] < pos0 + T or not pe.is_contiguous():
@@ -193,6 +195,37 @@ def lstm_step(x, h0, c0, w_ih, w_hh, b_ih, b_hh, want_gates=False, h_out=None):
     return (h1, c1, gates) if want_gates else (h1, c1)
 
 
+def lstm_step_into(x, h0, c0, w_ih, w_hh, b_ih, b_hh, h1, c1, gates):
+    """One fused LSTM step writing h', c' and the pre-activation gates into caller-provided contiguous blocks."""
+    lib = _lib.load()
+    B, E = x.shape
+    Hd = w_hh.shape[1]
+    for name, t in (("x", x), ("h1", h1), ("c1", c1), ("gates", gates), ("h0", h0), ("c0", c0)):
+        if t is not None and not _chk(t, name=name).is_contiguous():
+            raise RuntimeError(f"capdec lstm_step_into: {name} must be contiguous")
+    if h1.shape != (B, Hd) or c1.shape != (B, Hd) or gates.shape != (B, 4 * Hd):
+        raise RuntimeError("capdec lstm_step_into: output shapes do not match [B,Hd] / [B,4Hd]")
+    _lib.check(lib.capdec_lstm_step(x.data_ptr(), E, _ptr(h0), Hd, _ptr(c0), _chk(w_ih).data_ptr(),
+                                    _chk(w_hh).data_ptr(), _chk(b_ih).data_ptr(), _chk(b_hh).data_ptr(), B, E, Hd,
+                                    h1.data_ptr(), Hd, c1.data_ptr(), gates.data_ptr(), _stream()), "capdec_lstm_step")
+
+
+def lstm_step_bwd(gates, c0, c1, dh_out, dh_rec, dc_in, dgates):
+    """Backward of one LSTM step (see capdec_lstm_step_bwd).  Writes ``dgates`` [B,4Hd]; returns dc0 [B,Hd]
+    (written over ``dc_in`` when that is given)."""
+    lib = _lib.load()
+    B, Hd = c1.shape
+    for name, t in (("gates", gates), ("c1", c1), ("dgates", dgates), ("c0", c0), ("dh_rec", dh_rec), ("dc_in", dc_in)):
+        if t is not None and not _chk(t, name=name).is_contiguous():
+            raise RuntimeError(f"capdec lstm_step_bwd: {name} must be contiguous")
+    dc0 = dc_in if dc_in is not None else torch.empty_like(c1)
+    _lib.check(lib.capdec_lstm_step_bwd(gates.data_ptr(), _ptr(c0), c1.data_ptr(), _ptr(dh_out),
+                                        0 if dh_out is None else _row_stride(dh_out, "dh_out"), _ptr(dh_rec),
+                                        _ptr(dc_in), B, Hd, dgates.data_ptr(), dc0.data_ptr(), _stream()),
+               "capdec_lstm_step_bwd")
+    return dc0
+
+
 def vocab_argmax(x, W, b):
     """argmax_v (x W^T + b) per row without writing the logits; returns (idx int32 [M], val fp32 [M])."""
     lib = _lib.load()
@@ -288,6 +321,17 @@ def colsum(x, out):
     return out
 
 
+def group_sum(x, T):
+    """[G*T, E] -> [G, E]: sums of T consecutive rows."""
+    lib = _lib.load()
+    M, E = x.shape
+    if M % T or not x.is_contiguous():
+        raise RuntimeError("capdec group_sum: x must be a contiguous [G*T, E] tensor")
+    out = torch.empty((M // T, E), device=x.device, dtype=torch.float32)
+    _lib.check(lib.capdec_group_sum(_chk(x).data_ptr(), M // T, T, E, out.data_ptr(), _stream()), "capdec_group_sum")
+    return out
+
+
 def dropout(x, p, seed, out=None):
     lib = _lib.load()
     if not x.is_contiguous():
@@ -298,17 +342,20 @@ def dropout(x, p, seed, out=None):
     return out
 
 
-def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5):
-    """s = add + dropout(x); y = LN(s).  Returns (y, s, mean, rstd)."""
+def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5, x_div=1):
+    """s = add + dropout(x); y = LN(s).  Returns (y, s, mean, rstd).  With x_div > 1, x holds one row per
+    ``x_div`` consecutive rows of ``add`` (a per-sample row broadcast over its positions)."""
     lib = _lib.load()
-    M, E = x.shape
+    M, E = add.shape
+    if x.shape != ((M + x_div - 1) // x_div, E) or M % x_div:
+        raise RuntimeError(f"capdec add_layernorm_train: x {tuple(x.shape)} does not match add {tuple(add.shape)} / {x_div}")
     y = torch.empty((M, E), device=x.device, dtype=torch.float32)
     s = torch.empty_like(y)
     mean = torch.empty(M, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     if not x.is_contiguous() or not add.is_contiguous():
         raise RuntimeError("capdec add_layernorm_train: operands must be contiguous")
-    _lib.check(lib.capdec_add_layernorm_train(_chk(x).data_ptr(), _chk(add).data_ptr(), _chk(gamma).data_ptr(),
+    _lib.check(lib.capdec_add_layernorm_train(_chk(x).data_ptr(), x_div, _chk(add).data_ptr(), _chk(gamma).data_ptr(),
                                               _chk(beta).data_ptr(), eps, M, E, p, seed, y.data_ptr(), s.data_ptr(),
                                               mean.data_ptr(), rstd.data_ptr(), _stream()),
                "capdec_add_layernorm_train")

@@ -38,17 +38,22 @@ class CaptionTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.t = 0
-        (self.fc_a, self.split), self.fc_b = _head_spec(model)
-        named = dict(model.named_parameters())
+        self.rnn = getattr(model, "decoderRNN", None)          # CNN-RNN: the trainable module is the LSTM decoder
+        core = self.rnn if self.rnn is not None else model
+        self.core = core
+        named = dict(core.named_parameters())
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("capdec: the trainer needs the model on the GPU (HIP); there is no CPU path")
         # segments in the order the backward pass finishes them
-        L = len(model.decoder_layers)
         seg_names = [[n for n in named if n.startswith("fc2.")]]
-        for l in range(L - 1, -1, -1):
-            seg_names.append([n for n in named if n.startswith(f"decoder_layers.{l}.")])
-        seg_names.append(["decoder_embedding.weight"])
+        if self.rnn is not None:
+            seg_names.append([n for n in named if n.startswith("lstm.")] + ["embed.weight"])
+        else:
+            (self.fc_a, self.split), self.fc_b = _head_spec(model)
+            for l in range(len(model.decoder_layers) - 1, -1, -1):
+                seg_names.append([n for n in named if n.startswith(f"decoder_layers.{l}.")])
+            seg_names.append(["decoder_embedding.weight"])
         seg_names.append([n for n in named if n.split(".")[0] in ("fc1", "fc_vit", "fc_cnn", "fc_yolo", "batchnorm")])
         flat_names = [n for seg in seg_names for n in seg]
         missing = set(named) - set(flat_names)
@@ -93,6 +98,35 @@ class CaptionTrainer:
         self.flat_g.zero_()
         ids = captions[:, :-1].contiguous()
         tgt = captions[:, 1:].contiguous()
+        if self.rnn is not None:
+            loss = self._rnn_step(feats, ids, tgt)
+        else:
+            loss = self._tf_step(feats, ids, tgt)
+        # ---- Adam over the flat buffers (DDP semantics: mean of the per-rank gradients) ----
+        ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1],
+                      self.eps, grad_scale=1.0 / self.world)
+        return loss
+
+    def _rnn_step(self, feats, ids, tgt):
+        """CNN-RNN (reference cnnrnn_model.py:20-34): dropout -> fc1 -> BatchNorm, LSTM over [image, captions]."""
+        rnn = self.rnn
+        p = rnn.dropout.p
+        x0, htape = AG.head_forward(rnn, [(rnn.fc1, 0, feats.shape[1])], feats, True, AG.draw_seed() if p > 0 else 0)
+        h, tape = AG.rnn_forward(rnn, x0, ids, p, AG.draw_seed() if p > 0 else 0)
+        loss, saved = AG.vocab_loss(rnn, h, tgt.t().contiguous(), self.pad_idx)      # rows of h are time-major
+        works = []
+        dh = AG.vocab_loss_bwd(rnn, h, saved, self.grads)
+        self._reduce_segment(0, works)
+        dx0 = AG.rnn_backward(rnn, tape, dh, self.grads)
+        self._reduce_segment(1, works)
+        AG.head_backward(rnn, ["fc1"], htape, dx0, self.grads)
+        self._reduce_segment(2, works)
+        for w in works:
+            w.wait()
+        return loss
+
+    def _tf_step(self, feats, ids, tgt):
+        model = self.model
         p = model.dropout.p
         # ---- forward ----
         parts = [(getattr(model, self.fc_a), 0, self.split if self.fc_b else feats.shape[1])]
@@ -117,9 +151,6 @@ class CaptionTrainer:
         self._reduce_segment(len(self.segments) - 1, works)          # head
         for w in works:
             w.wait()
-        # ---- Adam over the flat buffers (DDP semantics: mean of the per-rank gradients) ----
-        ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1],
-                      self.eps, grad_scale=1.0 / self.world)
         return loss
 
     def grad_bytes(self):

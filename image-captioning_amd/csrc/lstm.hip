@@ -138,6 +138,38 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     }
 }
 
+struct LstmBwdArgs {
+    const float* gates; const float* c0; const float* c1;
+    const float* dh_out; int64_t lddh; const float* dh_rec; const float* dc_in;
+    int B, Hd;
+    float* dgates; float* dc0;
+};
+
+// Pointwise backward of one step: one thread per (sample, unit); recomputes the activations from the
+// saved pre-activation gates.
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs a) {
+    const int64_t n = (int64_t)a.B * a.Hd;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int i = (int)(idx / a.Hd), u = (int)(idx - (int64_t)i * a.Hd);
+    const float* gp = a.gates + (int64_t)i * 4 * a.Hd + u;
+    const float si = sigmoidf_(gp[0]), sf = sigmoidf_(gp[a.Hd]);
+    const float tg = tanhf(gp[2 * a.Hd]), so = sigmoidf_(gp[3 * a.Hd]);
+    const float cp = a.c0 ? a.c0[idx] : 0.f;
+    const float tc = tanhf(a.c1[idx]);
+    float dh = 0.f;
+    if (a.dh_out) dh += a.dh_out[(int64_t)i * a.lddh + u];
+    if (a.dh_rec) dh += a.dh_rec[idx];
+    float dc = dh * so * (1.f - tc * tc);
+    if (a.dc_in) dc += a.dc_in[idx];
+    float* dg = a.dgates + (int64_t)i * 4 * a.Hd + u;
+    dg[0] = dc * tg * si * (1.f - si);
+    dg[a.Hd] = dc * cp * sf * (1.f - sf);
+    dg[2 * a.Hd] = dc * si * (1.f - tg * tg);
+    dg[3 * a.Hd] = dh * tc * so * (1.f - so);
+    a.dc0[idx] = dc * sf;
+}
+
 }  // namespace
 
 extern "C" int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, const float* w_ih,
@@ -160,6 +192,19 @@ extern "C" int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, in
     dim3 grid((Hd + TU - 1) / TU, (B + TB - 1) / TB);
     if (vec) hipLaunchKernelGGL(lstm_step_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(lstm_step_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int capdec_lstm_step_bwd(const float* gates, const float* c0, const float* c1, const float* dh_out,
+                                    int64_t lddh, const float* dh_rec, const float* dc_in, int B, int Hd,
+                                    float* dgates, float* dc0, void* stream) {
+    CAPDEC_REQUIRE(gates && c1 && dgates && dc0 && B >= 0 && Hd >= 1);
+    CAPDEC_REQUIRE(!dh_out || lddh >= Hd);
+    if (B == 0) return 0;
+    LstmBwdArgs a{gates, c0, c1, dh_out, lddh, dh_rec, dc_in, B, Hd, dgates, dc0};
+    const int64_t n = (int64_t)B * Hd;
+    hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

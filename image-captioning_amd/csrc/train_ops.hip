@@ -32,14 +32,14 @@ constexpr int LN_MAXV = 8;
 __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int M, int E,
-                                                           float p, uint64_t seed, float* __restrict__ y,
+                                                           int x_div, float p, uint64_t seed, float* __restrict__ y,
                                                            float* __restrict__ s_out, float* __restrict__ mean_out,
                                                            float* __restrict__ rstd_out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     const int nv = E / 4;
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * E);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)(row / x_div) * E);
     const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (int64_t)row * E) : nullptr;
     const float inv_keep = 1.0f / (1.0f - p);
     f32x4 v[LN_MAXV];
@@ -198,6 +198,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && j < N) atomicAdd(&out[j], red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+// ---- sums of consecutive row groups: out[g, :] = sum_{t<T} x[g*T + t, :]  (gradient of a row broadcast) ----
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ x, int G, int T, int E,
+                                                        float* __restrict__ out) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= G) return;
+    const int nv = E / 4;
+    for (int c = lane; c < nv; c += 64) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) acc += reinterpret_cast<const f32x4*>(x + ((int64_t)g * T + t) * E)[c];
+        reinterpret_cast<f32x4*>(out + (int64_t)g * E)[c] = acc;
+    }
 }
 
 // ---- embedding backward: demb[ids[r], :] += dx[r, :] ----------------------------------------------
@@ -457,16 +471,17 @@ int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, 
     return 0;
 }
 
-int capdec_add_layernorm_train(const float* x, const float* add, const float* gamma, const float* beta, float eps,
-                               int M, int E, float p, uint64_t seed, float* y, float* s_out, float* mean, float* rstd,
-                               void* stream) {
+int capdec_add_layernorm_train(const float* x, int x_div, const float* add, const float* gamma, const float* beta,
+                               float eps, int M, int E, float p, uint64_t seed, float* y, float* s_out, float* mean,
+                               float* rstd, void* stream) {
     CAPDEC_REQUIRE(x && gamma && beta && y && M >= 0 && E >= 4 && E % 4 == 0 && E <= 256 * LN_MAXV && p >= 0.f && p < 1.f);
+    CAPDEC_REQUIRE(x_div >= 1);
     if (!capdec_aligned16(x) || !capdec_aligned16(y) || !capdec_aligned16(gamma) || !capdec_aligned16(beta) ||
         (add && !capdec_aligned16(add)) || (s_out && !capdec_aligned16(s_out)))
         return CAPDEC_EALIGN;
     if (M == 0) return 0;
     hipLaunchKernelGGL(ln_train_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
-                       eps, M, E, p, seed, y, s_out, mean, rstd);
+                       eps, M, E, x_div, p, seed, y, s_out, mean, rstd);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -491,6 +506,15 @@ int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* s
     if (M == 0) return 0;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0,
                        (hipStream_t)stream, x, ldx, M, N, out);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_group_sum(const float* x, int G, int T, int E, float* out, void* stream) {
+    CAPDEC_REQUIRE(x && out && G >= 0 && T >= 1 && E >= 4 && E % 4 == 0);
+    if (!capdec_aligned16(x) || !capdec_aligned16(out)) return CAPDEC_EALIGN;
+    if (G == 0) return 0;
+    hipLaunchKernelGGL(group_sum_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, G, T, E, out);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

@@ -157,10 +157,12 @@ int capdec_bn_train_forward(const float* x, const float* gamma, const float* bet
  * bias and embedding gradients) are ACCUMULATED into their outputs with float atomics: zero them first.
  * ------------------------------------------------------------------------------------------ */
 int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, void* stream);
-/* s = add + dropout_p(x) ; y = LayerNorm(s) ; s_out/mean/rstd (nullable) are saved for the backward pass */
-int capdec_add_layernorm_train(const float* x, const float* add, const float* gamma, const float* beta, float eps,
-                               int M, int E, float p, uint64_t seed, float* y, float* s_out, float* mean, float* rstd,
-                               void* stream);
+/* s = add + dropout_p(x) ; y = LayerNorm(s) ; s_out/mean/rstd (nullable) are saved for the backward pass.
+ * Row r of the sum reads row r / x_div of x (x_div = T broadcasts one row per sample over its T positions, the
+ * single-memory-row cross-attention output); the dropout mask is still drawn per element of the [M,E] sum. */
+int capdec_add_layernorm_train(const float* x, int x_div, const float* add, const float* gamma, const float* beta,
+                               float eps, int M, int E, float p, uint64_t seed, float* y, float* s_out, float* mean,
+                               float* rstd, void* stream);
 /* d_add = dLN/ds ; d_x = d_add * dropout mask (same p, seed as the forward) ; dgamma/dbeta accumulated */
 int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                          int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma, float* dbeta,
@@ -168,6 +170,8 @@ int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, con
 /* out[j] += sum_i x[i*ldx + j] */
 int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream);
 /* demb[ids[r],:] += dx[r,:]  (nn.Embedding backward, transformer.py:126 / cnnrnn_model.py:27) */
+/* out[g,:] = sum over t < T of x[g*T + t, :]  (gradient of a row that was broadcast over T positions) */
+int capdec_group_sum(const float* x, int G, int T, int E, float* out, void* stream);
 int capdec_embed_bwd(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb, void* stream);
 int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma, const float* save_mean,
                              const float* save_rstd, int B, int C, float* dx, float* dgamma, float* dbeta,
@@ -195,6 +199,16 @@ int capdec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, const float* w_ih,
                      const float* w_hh, const float* b_ih, const float* b_hh, int B, int E, int Hd, float* h1,
                      int64_t ldh1, float* c1, float* gates_out, void* stream);
+
+/* Backward of one capdec_lstm_step (autograd of nn.LSTM inside DecoderRNN.forward, cnnrnn_model.py:29-30):
+ * gates [B,4Hd] = the pre-activations saved by the forward step, c0 (NULL = zero) / c1 the cell state before /
+ * after it.  The gradient reaching h' is dh_out (row stride lddh; NULL = none, e.g. the image step whose output
+ * is discarded) + dh_rec (from the following step; NULL = none); dc_in is the gradient reaching c' from the
+ * following step (NULL = none).  Writes dgates [B,4Hd] (gradient of the pre-activations) and dc0 [B,Hd]
+ * (element-wise: dc0 may alias dc_in). */
+int capdec_lstm_step_bwd(const float* gates, const float* c0, const float* c1, const float* dh_out, int64_t lddh,
+                         const float* dh_rec, const float* dc_in, int B, int Hd, float* dgates, float* dc0,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole-loop greedy decoders.  One call enqueues every kernel of every step; the host never

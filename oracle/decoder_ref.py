@@ -233,15 +233,18 @@ def rnn_image_state(sd: SD, feats: torch.Tensor, training: bool = False):
     return h, c, new
 
 
-def decoder_rnn_forward(sd: SD, feats: torch.Tensor, ids: torch.Tensor, training: bool = False) -> torch.Tensor:
-    """``DecoderRNN.forward`` (cnnrnn_model.py:20-34): logits [B,T,V]."""
-    h, c, _ = rnn_image_state(sd, feats, training)
+def decoder_rnn_forward(sd: SD, feats: torch.Tensor, ids: torch.Tensor, training: bool = False,
+                        with_buffers: bool = False):
+    """``DecoderRNN.forward`` (cnnrnn_model.py:20-34): logits [B,T,V]; with ``with_buffers`` also the updated
+    BatchNorm buffers of a training-mode call."""
+    h, c, new = rnn_image_state(sd, feats, training)
     emb = sd["embed.weight"][ids]
     outs = []
     for t in range(ids.shape[1]):
         h, c = lstm_cell(emb[:, t], h, c, *_lstm_w(sd))
         outs.append(h)
-    return linear(torch.stack(outs, dim=1), sd["fc2.weight"], sd["fc2.bias"])
+    logits = linear(torch.stack(outs, dim=1), sd["fc2.weight"], sd["fc2.bias"])
+    return (logits, new) if with_buffers else logits
 
 
 def cnnrnn_greedy_ids(sd: SD, feats: torch.Tensor, max_length: int, sos: int = SOS, eos: int = EOS) -> List[List[int]]:

@@ -58,15 +58,16 @@ def test_f4_logits_loss_and_all_gradients_via_autograd(S):
             assert float(dec.decoder_layers[l].cross_attn.W_k.weight.grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("S", [1, 5])
-def test_f4_fused_loss_path(S):
-    """Projection + log-sum-exp + NLL without logits, and its backward, against the same golden vectors."""
+@pytest.mark.parametrize("S,shortcut", [(1, True), (1, False), (5, True)])
+def test_f4_fused_loss_path(S, shortcut):
+    """Projection + log-sum-exp + NLL without logits, and its backward, against the same golden vectors; with one
+    memory row both the closed form of the cross-attention sub-layer and the general kernels are checked."""
     from capdec import autograd as AG
     fx = load_golden("f4_decoder_forward")
     dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
     caps = t(fx["captions"]).cuda()
     enc = t(fx[f"enc_S{S}"]).cuda()
-    x, tape = AG.tf_forward(dec, enc, caps[:, :-1].contiguous(), 0.0, 0)
+    x, tape = AG.tf_forward(dec, enc, caps[:, :-1].contiguous(), 0.0, 0, single_row_shortcut=shortcut)
     loss, saved = AG.vocab_loss(dec, x, caps[:, 1:].contiguous())
     close(loss[0], fx[f"loss_S{S}"], rtol=1e-5, what="loss")
     grads = {}
@@ -227,3 +228,63 @@ def test_trainer_steps_match_oracle_training_loop():
             if not k.endswith(("W_k.bias", "fc_vit.bias", "fc_cnn.bias", "batchnorm.running_mean")):
                 assert float(d.mean()) <= 2e-6, (k, float(d.mean()))
     assert int(got["batchnorm.num_batches_tracked"]) == 4
+
+
+def _rnn_from_fixture(fx):
+    from models.cnnrnn_model import CNNtoRNN
+    sd = sub_sd(fx, "sd__")
+    Hd, E = sd["lstm.weight_hh_l0"].shape[1], sd["embed.weight"].shape[1]
+    m = CNNtoRNN(E, Hd, sd["embed.weight"].shape[0])
+    m.decoderRNN.dropout.p = 0.0
+    m.decoderRNN.load_state_dict(sd)
+    return m.cuda()
+
+
+def test_f7_cnn_rnn_train_logits_loss_and_all_gradients():
+    """DecoderRNN.forward in training mode (reference cnnrnn_model.py:20-34) + CrossEntropyLoss + backward through
+    the LSTM, the embedding and the BatchNorm head, against the reference's autograd."""
+    fx = load_golden("f7_decoder_rnn")
+    m = _rnn_from_fixture(fx).train()
+    feats, caps = t(fx["feats"]).cuda(), t(fx["captions"]).cuda()
+    logits = m(feats, caps[:, :-1])
+    close(logits, fx["logits_train"], what="logits")
+    V = logits.shape[-1]
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, V), caps[:, 1:].reshape(-1), ignore_index=0)
+    close(loss, fx["loss_train"], rtol=1e-5, what="loss")
+    loss.backward()
+    n = _check_grads(m.decoderRNN.named_parameters(), fx, "grad__{}", rtol=2e-4)
+    assert n == len(list(m.parameters()))
+
+
+def test_cnn_rnn_trainer_matches_oracle_training_loop():
+    """CaptionTrainer on CNNtoRNN (fused loss on time-major rows, flat buffers, HIP Adam) against the oracle forward +
+    torch autograd + torch.optim.Adam on the CPU."""
+    from capdec.trainer import CaptionTrainer
+    from oracle import decoder_ref as R
+    fx = load_golden("f7_decoder_rnn")
+    m = _rnn_from_fixture(fx)
+    feats, caps = t(fx["feats"]), t(fx["captions"])
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k)
+          for k, v in sub_sd(fx, "sd__").items()}
+    opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=1e-3)
+    ref_losses = []
+    for _ in range(3):
+        logits, new = R.decoder_rnn_forward(sd, feats, caps[:, :-1], training=True, with_buffers=True)
+        loss = R.caption_loss(logits, caps[:, 1:])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for k, v in new.items():
+            sd[k] = v
+        ref_losses.append(float(loss.detach()))
+    tr = CaptionTrainer(m, lr=1e-3)
+    losses = [float(tr.step(feats.cuda(), caps.cuda()).item()) for _ in range(3)]
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-4 * abs(b), (losses, ref_losses)
+    got = m.decoderRNN.state_dict()
+    for k, v in sd.items():
+        if v.is_floating_point():
+            d = (got[k].detach().cpu().double() - v.detach().double()).abs()
+            assert float(d.max()) <= 2.2 * 1e-3 * 3, (k, float(d.max()))
+            if k != "batchnorm.running_mean":
+                assert float(d.mean()) <= 3e-6, (k, float(d.mean()))
