@@ -17,11 +17,61 @@
 
 namespace {
 
+// Workgroup -> tile map.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2, so a
+// plain (x,y) grid spreads the tiles that share an operand slice over all eight L2s and every one of them
+// fetches that slice.  Here workgroup L belongs to XCD L & 7 and takes the (L >> 3)-th tile of that XCD's own
+// sequence; the sequences are cut so that tiles sharing operand rows run on one XCD, back to back:
+//   by_z == 0: the (ni x nj) tile grid of every z is cut into super-blocks of si x sj tiles dealt round-robin to
+//              the XCDs; a super-block reads si + sj operand slices for si*sj tiles;
+//   by_z == 1: (split-K) XCD k takes the z planes k, k+8, ...: a plane's operand k-range is read by one L2 only.
+// The XCD assignment is a performance assumption only; any placement computes the same tiles.
+struct TileMap {
+    int ni, nj, nz, si, sj, nsj, per_z, by_z;
+};
+
+__device__ __forceinline__ bool tile_of_block(const TileMap& m, unsigned L, int& z, int& ti, int& tj) {
+    if (m.by_z) {
+        const int xcd = L & 7, slot = L >> 3;
+        const int nt = m.ni * m.nj;
+        const int zq = slot / nt, t = slot - zq * nt;
+        z = zq * 8 + xcd;
+        ti = t / m.nj;
+        tj = t - ti * m.nj;
+        return z < m.nz;
+    }
+    z = L / m.per_z;
+    L -= z * m.per_z;
+    const int xcd = L & 7, slot = L >> 3;
+    const int per = m.si * m.sj;
+    const int sb = slot / per, w = slot - sb * per;
+    const int G = sb * 8 + xcd;
+    const int sbi = G / m.nsj, sbj = G - sbi * m.nsj;
+    const int wi = w / m.sj;
+    ti = sbi * m.si + wi;
+    tj = sbj * m.sj + (w - wi * m.sj);
+    return ti < m.ni && tj < m.nj;
+}
+
+// host side: fills the map, returns the 1-D grid size
+unsigned make_tile_map(TileMap& m, int ni, int nj, int nz, bool by_z) {
+    m.ni = ni; m.nj = nj; m.nz = nz;
+    m.by_z = by_z ? 1 : 0;
+    m.sj = nj < 8 ? nj : 8;
+    m.nsj = (nj + m.sj - 1) / m.sj;
+    m.si = 1;
+    while (m.si < 8 && (long)((ni + 2 * m.si - 1) / (2 * m.si)) * m.nsj >= 128) m.si *= 2;
+    const int nsb = ((ni + m.si - 1) / m.si) * m.nsj;
+    m.per_z = 8 * ((nsb + 7) / 8) * m.si * m.sj;
+    if (by_z) return (unsigned)(8 * ((nz + 7) / 8)) * (unsigned)(ni * nj);
+    return (unsigned)m.per_z * (unsigned)nz;
+}
+
 struct GemmKArgs {
     capdec_gemm_group g[4];
     int K;
     int flags;
-    int nsplit;          // k-range splits per group (blockIdx.z = group * nsplit + split); > 1 only with ATOMIC
+    int nsplit;          // k-range splits per group (z = group * nsplit + split); > 1 only with ATOMIC
+    TileMap map;
     capdec_gemm_extra x;
 };
 
@@ -248,10 +298,12 @@ __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >
 template <int WM, int WI, int WJ, int BK, bool VEC, bool TP, bool TQ, int KG>
 __global__ __launch_bounds__(128 * WM * KG) void gemm_kernel(GemmKArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int grp = blockIdx.z / args.nsplit, split = blockIdx.z - grp * args.nsplit;
+    int z, tile_i, tile_j;
+    if (!tile_of_block(args.map, blockIdx.x, z, tile_i, tile_j)) return;
+    const int grp = z / args.nsplit, split = z - grp * args.nsplit;
     const capdec_gemm_group& g = args.g[grp];
     constexpr int BI = 32 * WM * WI, BJ = 64 * WJ;
-    const int i0 = blockIdx.y * BI, j0 = blockIdx.x * BJ;
+    const int i0 = tile_i * BI, j0 = tile_j * BJ;
     // rows_dev: the number of live rows is only known on the device (decode steps that re-run a few rows)
     const int nI = args.x.rows_dev ? min(g.I, args.x.rows_dev[0]) : g.I;
     if (i0 >= nI || j0 >= g.J) return;   // groups of different size share the grid
@@ -317,10 +369,12 @@ template <int WI, int WJ, int BK, bool VEC, int MODE>
 __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restrict__ W, const float* __restrict__ x,
                                                            int64_t ldx, const float* __restrict__ bias, int V, int M,
                                                            int K, float* __restrict__ out_a, void* __restrict__ out_b,
-                                                           int ntiles) {
+                                                           int ntiles, TileMap map) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BI = 64 * WI, BJ = 64 * WJ;
-    const int i0 = blockIdx.y * BI, j0 = blockIdx.x * BJ;
+    int z, tile_i, tile_j;
+    if (!tile_of_block(map, blockIdx.x, z, tile_i, tile_j)) return;
+    const int i0 = tile_i * BI, j0 = tile_j * BJ;
     f32x16 acc[WI][WJ];
     mainloop<2, WI, WJ, BK, VEC>(W, x, (int64_t)K, ldx, V, M, K, i0, j0, 0, (K + BK - 1) / BK, lds, acc);
 
@@ -387,7 +441,7 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restri
     const int t = threadIdx.x;
     if (t < BJ && j0 + t < M) {
         float a0 = sm_a[t], a1 = sm_a[BJ + t];
-        const int64_t o = (int64_t)(j0 + t) * ntiles + blockIdx.y;
+        const int64_t o = (int64_t)(j0 + t) * ntiles + tile_i;
         if (MODE == 0) {
             int b0 = reinterpret_cast<int*>(sm_b)[t], b1 = reinterpret_cast<int*>(sm_b)[BJ + t];
             argmax_merge(a0, b0, a1, b1);
@@ -422,40 +476,57 @@ __global__ __launch_bounds__(256) void argmax_finalize_kernel(const float* __res
     }
 }
 
-// one wavefront per row: lse from per-tile (max, sum), target logit by a K-long dot product
+// one wavefront per row, NLL_ROWS rows per workgroup: lse from per-tile (max, sum), target logit by a K-long dot
+// product; the loss sum and the count leave the workgroup as ONE pair of atomics (same-address atomics serialise)
+constexpr int NLL_ROWS = 32;
+
 __global__ __launch_bounds__(256) void nll_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
                                                            int M, int ntiles, const float* __restrict__ x, int64_t ldx,
                                                            const float* __restrict__ W, const float* __restrict__ bias,
                                                            int K, const int64_t* __restrict__ targets,
                                                            int64_t ignore_index, float* __restrict__ lse_out,
                                                            float* __restrict__ nll_out, float* __restrict__ loss_sum) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= M) return;
-    float mx = -INFINITY;
-    for (int t = lane; t < ntiles; t += 64) mx = fmaxf(mx, pm[(int64_t)row * ntiles + t]);
-    mx = wave_max(mx);
-    float s = 0.f;
-    for (int t = lane; t < ntiles; t += 64) {
-        const float m = pm[(int64_t)row * ntiles + t];
-        if (m > -INFINITY) s += ps[(int64_t)row * ntiles + t] * expf(m - mx);
-    }
-    s = wave_sum(s);
-    const float lse = mx + logf(s);
-    const int64_t tg = targets[row];
-    float nll = 0.f;
-    if (tg != ignore_index) {
-        float d = 0.f;
-        for (int k = lane; k < K; k += 64) d += x[(int64_t)row * ldx + k] * W[tg * (int64_t)K + k];
-        d = wave_sum(d) + bias[tg];
-        nll = lse - d;
+    __shared__ float red[2][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc_nll = 0.f, acc_cnt = 0.f;
+    for (int rr = wave; rr < NLL_ROWS; rr += 4) {
+        const int row = blockIdx.x * NLL_ROWS + rr;
+        if (row >= M) break;
+        float mx = -INFINITY;
+        for (int t = lane; t < ntiles; t += 64) mx = fmaxf(mx, pm[(int64_t)row * ntiles + t]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int t = lane; t < ntiles; t += 64) {
+            const float m = pm[(int64_t)row * ntiles + t];
+            if (m > -INFINITY) s += ps[(int64_t)row * ntiles + t] * expf(m - mx);
+        }
+        s = wave_sum(s);
+        const float lse = mx + logf(s);
+        const int64_t tg = targets[row];
+        float nll = 0.f;
+        if (tg != ignore_index) {
+            float d = 0.f;
+            for (int k = lane; k < K; k += 64) d += x[(int64_t)row * ldx + k] * W[tg * (int64_t)K + k];
+            d = wave_sum(d) + bias[tg];
+            nll = lse - d;
+            acc_nll += nll;
+            acc_cnt += 1.f;
+        }
+        if (lane == 0) {
+            if (lse_out) lse_out[row] = lse;
+            if (nll_out) nll_out[row] = nll;
+        }
     }
     if (lane == 0) {
-        if (lse_out) lse_out[row] = lse;
-        if (nll_out) nll_out[row] = nll;
-        if (tg != ignore_index && loss_sum) {
-            atomicAdd(&loss_sum[0], nll);
-            atomicAdd(&loss_sum[1], 1.f);
+        red[0][wave] = acc_nll;
+        red[1][wave] = acc_cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_sum) {
+        const float c = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (c > 0.f) {
+            atomicAdd(&loss_sum[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+            atomicAdd(&loss_sum[1], c);
         }
     }
 }
@@ -482,7 +553,7 @@ int launch_gemm_cfg(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hip
         a.nsplit = (int)(want < 1 ? 1 : (want > cap ? cap : want));
         if (a.nsplit > 64) a.nsplit = 64;
     }
-    dim3 grid(tj, ti, ngroups * a.nsplit);
+    dim3 grid(make_tile_map(a.map, ti, tj, ngroups * a.nsplit, a.nsplit >= 8), 1, 1);
     constexpr size_t smem = lds_floats<WM, WI, WJ, BK, TP, TQ, KG>() * sizeof(float);
     static const bool ready = allow_lds(gemm_kernel<WM, WI, WJ, BK, true, TP, TQ, KG>, smem) &&
                               allow_lds(gemm_kernel<WM, WI, WJ, BK, false, TP, TQ, KG>, smem);
@@ -493,7 +564,7 @@ int launch_gemm_cfg(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hip
     return 0;
 }
 
-// Tile choice.  cfg = 0: automatic; otherwise force: 11 / 22 / 216 = 64x64 (BK 32), 128x128 (BK 32), 128x128 (BK 16);
+// Tile choice.  cfg = 0: automatic; otherwise force: 11 / 116 = 64x64 (BK 32 / 16), 22 / 216 = 128x128 (BK 32 / 16),
 // 32 = 32x64 tile with the k-loop split over the workgroup's two wave pairs.
 int g_force_cfg = 0;
 
@@ -501,15 +572,19 @@ template <bool TP, bool TQ>
 int launch_gemm_layout(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hipStream_t s) {
     int cfg = g_force_cfg;
     if (cfg == 0) {
-        // 64x64 tiles at four workgroups per CU hide latency best at every size measured; when that grid would
-        // leave CUs idle (fewer than two tiles per CU), halve the tile so twice as many CUs share the MFMA work
+        // Measured on MI355X at the decoder's shapes: 64x64 tiles at BK 16 (20 KiB of LDS, so every tile of a
+        // 1280-tile grid is resident at once and nothing runs as a lone tail) win wherever there is at least one
+        // tile per CU; below that, halving the tile lets twice as many CUs share the MFMA work.  Split-K weight
+        // gradients keep BK 32 (their k loop is long), and 128x128 tiles pay off only for very large outputs.
         const long tiles64 = (long)((maxI + 63) / 64) * ((maxJ + 63) / 64) * ngroups;
         const bool atomic = (a.flags & CAPDEC_GEMM_ATOMIC) != 0;
-        cfg = (!atomic && tiles64 < 512) ? 32 : 11;
+        if (atomic) cfg = tiles64 >= 1024 ? 216 : 11;
+        else cfg = tiles64 < 256 ? 32 : 116;
     }
     if (cfg == 22) return launch_gemm_cfg<2, 2, 2, 32, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
     if (cfg == 216) return launch_gemm_cfg<2, 2, 2, 16, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
     if (cfg == 32) return launch_gemm_cfg<1, 1, 1, 32, TP, TQ, 2>(a, ngroups, maxI, maxJ, vec, s);
+    if (cfg == 116) return launch_gemm_cfg<2, 1, 1, 16, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
     return launch_gemm_cfg<2, 1, 1, 32, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
 }
 
@@ -558,7 +633,7 @@ int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int 
 extern "C" {
 
 int capdec_gemm_force_config(int cfg) {
-    CAPDEC_REQUIRE(cfg == 0 || cfg == 11 || cfg == 22 || cfg == 216 || cfg == 32);
+    CAPDEC_REQUIRE(cfg == 0 || cfg == 11 || cfg == 22 || cfg == 216 || cfg == 32 || cfg == 116);
     g_force_cfg = cfg;
     return 0;
 }
@@ -586,10 +661,11 @@ static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const floa
     constexpr size_t smem_w = lds_floats<2, 2, 2, VBK, false, false, 1>() * sizeof(float);
     constexpr size_t smem_n = lds_floats<2, 2, 1, VBK, false, false, 1>() * sizeof(float);
     const size_t smem = wide ? smem_w : smem_n;
-    dim3 grid(wide ? (M + 127) / 128 : (M + 63) / 64, nt, 1);
+    TileMap map;
+    dim3 grid(make_tile_map(map, nt, wide ? (M + 127) / 128 : (M + 63) / 64, 1, false), 1, 1);
 #define CAPDEC_VR(WJ_, VEC_, MODE_)                                                                                    \
     hipLaunchKernelGGL((vocab_reduce_kernel<2, WJ_, VBK, VEC_, MODE_>), grid, dim3(256), smem, s, W, x, ldx, bias, V, \
-                       M, K, out_a, out_b, nt)
+                       M, K, out_a, out_b, nt, map)
     if (mode == 0) {
         if (wide) { if (vec) CAPDEC_VR(2, true, 0); else CAPDEC_VR(2, false, 0); }
         else      { if (vec) CAPDEC_VR(1, true, 0); else CAPDEC_VR(1, false, 0); }
@@ -627,7 +703,7 @@ int capdec_nll_finalize(const float* part_max, const float* part_sum, int M, int
                         float* lse, float* nll, float* loss_sum, void* stream) {
     CAPDEC_REQUIRE(part_max && part_sum && x && W && bias && targets && M >= 0 && ntiles >= 1 && K >= 1);
     if (M == 0) return 0;
-    hipLaunchKernelGGL(nll_finalize_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, part_max, part_sum,
+    hipLaunchKernelGGL(nll_finalize_kernel, dim3((M + NLL_ROWS - 1) / NLL_ROWS), dim3(256), 0, (hipStream_t)stream, part_max, part_sum,
                        M, ntiles, x, ldx, W, bias, K, targets, ignore_index, lse, nll, loss_sum);
     CAPDEC_LAUNCH_CHECK();
     return 0;

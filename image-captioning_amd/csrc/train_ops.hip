@@ -7,23 +7,39 @@
 
 namespace {
 
-// counter-based uniform in [0,1): splitmix64 of (seed, element index); the same (seed, index) gives the
-// same mask in the forward and the backward pass, so masks are never stored
-__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ULL;
+// Counter-based dropout masks: one splitmix64 of (seed, element index / 4) yields four 16-bit uniforms, one per
+// element of an aligned group of four; an element is kept when its 16 bits are >= round(p * 65536).  The same
+// (seed, index) gives the same mask in the forward and the backward pass, so masks are never stored.
+__device__ __forceinline__ uint64_t rng_bits(uint64_t seed, uint64_t q) {
+    uint64_t z = seed + (q + 1) * 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z ^= z >> 31;
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
+    return z ^ (z >> 31);
 }
+__device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)(p * 65536.0f + 0.5f); }
 __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
-    return rng_uniform(seed, idx) >= p ? inv_keep : 0.f;
+    const unsigned u = (unsigned)(rng_bits(seed, idx >> 2) >> (16 * (idx & 3))) & 0xFFFFu;
+    return u >= drop_threshold(p) ? inv_keep : 0.f;
+}
+// the four scales of the aligned element group starting at idx0 (idx0 % 4 == 0)
+__device__ __forceinline__ f32x4 drop_scale4(uint64_t seed, uint64_t idx0, float p, float inv_keep) {
+    const uint64_t bits = rng_bits(seed, idx0 >> 2);
+    const unsigned thr = drop_threshold(p);
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = ((unsigned)(bits >> (16 * k)) & 0xFFFFu) >= thr ? inv_keep : 0.f;
+    return r;
 }
 
 __global__ void dropout_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed, float* __restrict__ y) {
     const float inv_keep = 1.0f / (1.0f - p);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = x[i] * drop_scale(seed, (uint64_t)i, p, inv_keep);
+}
+__global__ void dropout4_kernel(const f32x4* __restrict__ x, int64_t n4, float p, uint64_t seed, f32x4* __restrict__ y) {
+    const float inv_keep = 1.0f / (1.0f - p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = x[i] * drop_scale4(seed, (uint64_t)i * 4, p, inv_keep);
 }
 
 // ---- LayerNorm forward for training: s = add + dropout(x); y = LN(s) ---------------------------------
@@ -51,9 +67,7 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
         if (c < nv) {
             v[u] = xr[c];
             if (p > 0.f) {
-                const uint64_t e0 = (uint64_t)row * E + 4 * c;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[u][k] *= drop_scale(seed, e0 + k, p, inv_keep);
+                v[u] *= drop_scale4(seed, (uint64_t)row * E + 4 * c, p, inv_keep);
             }
             if (ar) v[u] += ar[c];
             sum += v[u][0] + v[u][1] + v[u][2] + v[u][3];
@@ -149,9 +163,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (d_add) reinterpret_cast<f32x4*>(d_add + (int64_t)row * E)[c] = ds;
                 if (d_x) {
                     if (p > 0.f) {
-                        const uint64_t e0 = (uint64_t)row * E + 4 * c;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) ds[k] *= drop_scale(seed, e0 + k, p, inv_keep);
+                        ds *= drop_scale4(seed, (uint64_t)row * E + 4 * c, p, inv_keep);
                     }
                     reinterpret_cast<f32x4*>(d_x + (int64_t)row * E)[c] = ds;
                 }
@@ -183,21 +195,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // ---- column sums: out[j] += sum_i x[i*ldx + j]  (bias gradients) -------------------------------------
-constexpr int CS_ROWS = 256;
+// A workgroup sums CS_ROWS rows of a 256-column strip: 64 lanes x 16 B per row, four rows in flight per
+// wavefront (independent accumulators), one atomic per column and workgroup.
+constexpr int CS_ROWS = 128;
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
                                                      float* __restrict__ out) {
-    __shared__ float red[4][64];
+    __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
+    const int j = blockIdx.x * 256 + lane * 4;
     const int r0 = blockIdx.y * CS_ROWS;
     const int r1 = min(M, r0 + CS_ROWS);
-    float s = 0.f;
-    if (j < N)
-        for (int r = r0 + wave; r < r1; r += 4) s += x[(int64_t)r * ldx + j];
-    red[wave][lane] = s;
+    f32x4 s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (j < N) {
+        for (int r = r0 + wave; r < r1; r += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + 4 * u;
+                if (rr < r1) {
+                    const float* p = x + (int64_t)rr * ldx + j;
+                    if (VEC) s[u] += *reinterpret_cast<const f32x4*>(p);
+                    else
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (j + c < N) s[u][c] += p[c];
+                }
+            }
+        }
+    }
+    red[wave][lane] = (s[0] + s[1]) + (s[2] + s[3]);
     __syncthreads();
-    if (wave == 0 && j < N) atomicAdd(&out[j], red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (wave == 0 && j < N) {
+        const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (j + c < N) atomicAdd(&out[j + c], t[c]);
+    }
 }
 
 // ---- sums of consecutive row groups: out[g, :] = sum_{t<T} x[g*T + t, :]  (gradient of a row broadcast) ----
@@ -466,7 +502,11 @@ extern "C" {
 int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, void* stream) {
     CAPDEC_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f);
     if (n == 0) return 0;
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, p, seed, y);
+    if (n % 4 == 0 && capdec_aligned16(x) && capdec_aligned16(y))
+        hipLaunchKernelGGL(dropout4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const f32x4*>(x), n / 4, p, seed, reinterpret_cast<f32x4*>(y));
+    else
+        hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, p, seed, y);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -504,8 +544,10 @@ int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, con
 int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream) {
     CAPDEC_REQUIRE(x && out && M >= 0 && N >= 1 && ldx >= N);
     if (M == 0) return 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0,
-                       (hipStream_t)stream, x, ldx, M, N, out);
+    const bool vec = N % 4 == 0 && ldx % 4 == 0 && capdec_aligned16(x);
+    dim3 grid((N + 255) / 256, (M + CS_ROWS - 1) / CS_ROWS);
+    if (vec) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, out);
+    else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, out);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

@@ -81,7 +81,7 @@ typedef struct capdec_gemm_extra {
     const float* lse; const int64_t* tgt; const float* gscale; int64_t ignore_index;
     const int32_t* rows_dev;   /* nullable device scalar: only rows i < min(I, rows_dev[0]) are computed */
 } capdec_gemm_extra;
-/* Tuning hook for benchmarks: 0 = automatic tile choice, 11 = 64x64 (BK 32), 22 = 128x128 (BK 32), 216 = 128x128 (BK 16),
+/* Tuning hook for benchmarks: 0 = automatic tile choice, 11 / 116 = 64x64 (BK 32 / 16), 22 / 216 = 128x128 (BK 32 / 16),
  * 32 = 32x64 tile with its k-loop split over the two wave pairs.  Process-wide; not for production use. */
 int capdec_gemm_force_config(int cfg);
 int capdec_gemm_ex(const capdec_gemm_group* groups /*host*/, int ngroups, int K, int flags,

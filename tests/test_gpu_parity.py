@@ -383,7 +383,7 @@ def test_gemm_split_k_atomic_and_forced_tiles(ops):
     b, sc, sh = torch.randn(80, generator=g), torch.rand(80, generator=g) + 0.5, torch.randn(80, generator=g)
     ref = (x.double() @ W.double().t() + b.double()) * sc.double() + sh.double()
     try:
-        for cfg in (0, 11, 32, 22, 216):
+        for cfg in (0, 11, 116, 32, 22, 216):
             lib.capdec_gemm_force_config(cfg)
             y = ops.linear(x.cuda(), W.cuda(), b.cuda(), scale=sc.cuda(), shift=sh.cuda(), split_k=True)
             close(y, ref, what=f"split-k cfg {cfg}")
