@@ -157,19 +157,32 @@ def vocab_logits_bwd(dec, x, dlogits, grads):
     return _lin_bwd(grads, "fc2", dec.fc2, dlogits, x)
 
 
-def vocab_loss(dec, x, targets, ignore_index=0):
-    """Fused projection + CrossEntropyLoss(ignore_index) (reference train.py:216,254-256) without logits.
-    Returns (loss [1] device tensor, saved state for ``vocab_loss_bwd``)."""
-    lse, nll, sums = ops.vocab_nll(x, dec.fc2.weight, dec.fc2.bias, targets.reshape(-1), ignore_index)
+def vocab_loss(dec, x, targets, ignore_index=0, materialize=True):
+    """Projection + CrossEntropyLoss(ignore_index) (reference train.py:216,254-256).
+    Returns (loss [1] device tensor, saved state for ``vocab_loss_bwd``).
+
+    materialize=True (training): the logits are written once and turned in place into the softmax gradient, which
+    the backward pass contracts with fc2 and x; on this machine writing and re-reading 4*M*V bytes is several times
+    cheaper than recomputing the M x V x E contraction.  materialize=False: fused log-sum-exp + NLL, no logits
+    (evaluation loss; its backward recomputes the projection tile-wise)."""
+    tg = targets.reshape(-1).contiguous()
+    if materialize:
+        dlogits = ops.linear(x, dec.fc2.weight, dec.fc2.bias)
+        sums, _ = ops.softmax_nll_grad_(dlogits, tg, ignore_index)
+        loss, _ = ops.loss_finish(sums)
+        return loss, (dlogits,)
+    lse, nll, sums = ops.vocab_nll(x, dec.fc2.weight, dec.fc2.bias, tg, ignore_index)
     loss, gscale = ops.loss_finish(sums)
-    return loss, (lse, gscale, targets.reshape(-1).contiguous(), ignore_index)
+    return loss, (lse, gscale, tg, ignore_index)
 
 
 def vocab_loss_bwd(dec, x, saved, grads):
-    """d(loss)/dx; the [M,V] softmax gradient is recomputed tile-wise from the projection and the saved
-    log-sum-exp (one transient buffer), then contracted with fc2 and x."""
-    lse, gscale, targets, ignore_index = saved
-    dlogits = ops.softmax_grad_logits(x, dec.fc2.weight, dec.fc2.bias, lse, targets, gscale, ignore_index)
+    """d(loss)/dx and the fc2 gradients from what ``vocab_loss`` saved."""
+    if len(saved) == 1:
+        dlogits = saved[0]
+    else:
+        lse, gscale, targets, ignore_index = saved
+        dlogits = ops.softmax_grad_logits(x, dec.fc2.weight, dec.fc2.bias, lse, targets, gscale, ignore_index)
     return _lin_bwd(grads, "fc2", dec.fc2, dlogits, x)
 
 

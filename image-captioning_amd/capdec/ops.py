@@ -432,6 +432,22 @@ def softmax_grad_logits(x, W, b, lse, targets, gscale, ignore_index=0, out=None)
                     gscale=gscale, ignore_index=ignore_index)
 
 
+def softmax_nll_grad_(logits, targets, ignore_index=0):
+    """In place: logits [M,V] -> d(mean NLL)/d(logits).  Returns (sums [2] = (sum nll, n counted), gscale [1])."""
+    lib = _lib.load()
+    _chk(logits, name="logits")
+    _chk(targets, torch.int64, "targets")
+    M, V = logits.shape
+    if targets.numel() != M or not targets.is_contiguous():
+        raise RuntimeError("capdec softmax_nll_grad_: targets must be a contiguous [M] tensor")
+    sums = torch.zeros(2, device=logits.device, dtype=torch.float32)
+    gscale = torch.empty(1, device=logits.device, dtype=torch.float32)
+    _lib.check(lib.capdec_softmax_nll_grad(logits.data_ptr(), _row_stride(logits, "logits"), targets.data_ptr(), M, V,
+                                           ignore_index, sums.data_ptr(), gscale.data_ptr(), None, _stream()),
+               "capdec_softmax_nll_grad")
+    return sums, gscale
+
+
 def loss_finish(sums):
     lib = _lib.load()
     loss = torch.empty(1, device=sums.device, dtype=torch.float32)

@@ -495,6 +495,97 @@ inline int grid_for(int64_t n) {
     return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 
+// ---- materialised vocabulary loss: logits [M,V] -> d(mean NLL)/d(logits) in place ---------------------
+// count_targets: sums[1] = number of counted targets, gscale[0] = 1 / that number
+__global__ __launch_bounds__(256) void count_targets_kernel(const int64_t* __restrict__ targets, int M,
+                                                            int64_t ignore_index, float* __restrict__ sums,
+                                                            float* __restrict__ gscale) {
+    __shared__ int red[4];
+    int c = 0;
+    for (int i = threadIdx.x; i < M; i += 256) c += targets[i] != ignore_index ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float n = (float)(red[0] + red[1] + red[2] + red[3]);
+        sums[1] = n;
+        gscale[0] = 1.0f / n;
+    }
+}
+
+// One wavefront per row (SM_ROWS rows per workgroup): pass 1 keeps a running (max, sum exp) per lane and merges
+// them over the wave; pass 2 re-reads the row (cache-resident) and overwrites it with
+// (softmax - onehot(target)) * gscale, or zeros for an ignored target.  The row's NLL joins the workgroup's
+// partial, which leaves as one atomic.
+constexpr int SM_ROWS = 16;
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void softmax_nll_grad_kernel(float* __restrict__ logits, int64_t ld,
+                                                               const int64_t* __restrict__ targets, int M, int V,
+                                                               int64_t ignore_index, const float* __restrict__ gscale,
+                                                               float* __restrict__ sums, float* __restrict__ lse_out) {
+    __shared__ float red[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float gs = gscale[0];
+    float acc = 0.f;
+    for (int rr = wave; rr < SM_ROWS; rr += 4) {
+        const int row = blockIdx.x * SM_ROWS + rr;
+        if (row >= M) break;
+        float* lr = logits + (int64_t)row * ld;
+        float mx = -INFINITY, sm = 0.f;
+        if (VEC) {
+            const f32x4* l4 = reinterpret_cast<const f32x4*>(lr);
+            for (int c = lane; c < V / 4; c += 64) {
+                const f32x4 v = l4[c];
+                const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                if (m4 > mx) {
+                    sm *= __expf(mx - m4);
+                    mx = m4;
+                }
+                sm += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx);
+            }
+        } else {
+            for (int c = lane; c < V; c += 64) {
+                const float v = lr[c];
+                if (v > mx) {
+                    sm *= __expf(mx - v);
+                    mx = v;
+                }
+                sm += __expf(v - mx);
+            }
+        }
+        const float wm = wave_max(mx);
+        sm = wave_sum(mx > -INFINITY ? sm * __expf(mx - wm) : 0.f);
+        const float lse = wm + logf(sm);
+        const int64_t tg = targets[row];
+        const bool counted = tg != ignore_index;
+        const float tl = counted ? lr[tg] : 0.f;
+        // the target logit is in a register before any lane overwrites the row
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (counted && lane == 0) acc += lse - tl;
+        if (lane == 0 && lse_out) lse_out[row] = lse;
+        if (VEC) {
+            f32x4* l4 = reinterpret_cast<f32x4*>(lr);
+            for (int c = lane; c < V / 4; c += 64) {
+                f32x4 v = l4[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    v[k] = counted ? (__expf(v[k] - lse) - ((int64_t)(4 * c + k) == tg ? 1.f : 0.f)) * gs : 0.f;
+                l4[c] = v;
+            }
+        } else {
+            for (int c = lane; c < V; c += 64)
+                lr[c] = counted ? (__expf(lr[c] - lse) - ((int64_t)c == tg ? 1.f : 0.f)) * gs : 0.f;
+        }
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = red[0] + red[1] + red[2] + red[3];
+        if (t != 0.f) atomicAdd(&sums[0], t);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -601,6 +692,24 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
     hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((tq + 3) / 4)), dim3(256), 4 * 2 * Tk * sizeof(float), s, a);
     CAPDEC_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((tk + 3) / 4)), dim3(256), 4 * 2 * Tq * sizeof(float), s, a);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_softmax_nll_grad(float* logits, int64_t ld, const int64_t* targets, int M, int V, int64_t ignore_index,
+                            float* sums, float* gscale, float* lse_out, void* stream) {
+    CAPDEC_REQUIRE(logits && targets && sums && gscale && M >= 0 && V >= 1 && ld >= V);
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(count_targets_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, targets, M, ignore_index, sums,
+                       gscale);
+    const bool vec = V % 4 == 0 && ld % 4 == 0 && capdec_aligned16(logits);
+    const dim3 grid((M + SM_ROWS - 1) / SM_ROWS);
+    if (vec)
+        hipLaunchKernelGGL(softmax_nll_grad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, logits, ld, targets, M,
+                           V, ignore_index, gscale, sums, lse_out);
+    else
+        hipLaunchKernelGGL(softmax_nll_grad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, logits, ld, targets, M,
+                           V, ignore_index, gscale, sums, lse_out);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

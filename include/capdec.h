@@ -184,6 +184,12 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
                          float* dq, int64_t lddq, float* dk, int64_t lddk, int64_t sdk, float* dv, int64_t lddv,
                          int64_t sdv, int B, int H, int Tq, int Tk, int dkh, int causal, int causal_off,
                          const int32_t* ids, int64_t ldid, void* stream);
+/* Materialised form of the same loss (train.py:216,254-256) for training, where the backward pass needs the
+ * softmax anyway: logits [M,V] (row stride ld) are overwritten in place with d(mean NLL)/d(logits) =
+ * (softmax - onehot(target)) / n_counted (zero rows for ignored targets).  sums must be zeroed by the caller:
+ * sums[0] += sum of the rows' NLL, sums[1] = n_counted; gscale[0] = 1 / n_counted; lse_out [M] nullable. */
+int capdec_softmax_nll_grad(float* logits, int64_t ld, const int64_t* targets, int M, int V, int64_t ignore_index,
+                            float* sums, float* gscale, float* lse_out, void* stream);
 /* sums = (sum of nll, number of counted targets) from capdec_nll_finalize:
  * loss[0] = sums[0] / sums[1] (nn.CrossEntropyLoss mean over non-ignored targets), gscale[0] = 1 / sums[1] */
 int capdec_loss_finish(const float* sums, float* loss, float* gscale, void* stream);

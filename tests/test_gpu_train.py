@@ -58,8 +58,8 @@ def test_f4_logits_loss_and_all_gradients_via_autograd(S):
             assert float(dec.decoder_layers[l].cross_attn.W_k.weight.grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("S,shortcut", [(1, True), (1, False), (5, True)])
-def test_f4_fused_loss_path(S, shortcut):
+@pytest.mark.parametrize("S,shortcut,materialize", [(1, True, True), (1, False, False), (5, True, False), (5, True, True)])
+def test_f4_fused_loss_path(S, shortcut, materialize):
     """Projection + log-sum-exp + NLL without logits, and its backward, against the same golden vectors; with one
     memory row both the closed form of the cross-attention sub-layer and the general kernels are checked."""
     from capdec import autograd as AG
@@ -68,7 +68,7 @@ def test_f4_fused_loss_path(S, shortcut):
     caps = t(fx["captions"]).cuda()
     enc = t(fx[f"enc_S{S}"]).cuda()
     x, tape = AG.tf_forward(dec, enc, caps[:, :-1].contiguous(), 0.0, 0, single_row_shortcut=shortcut)
-    loss, saved = AG.vocab_loss(dec, x, caps[:, 1:].contiguous())
+    loss, saved = AG.vocab_loss(dec, x, caps[:, 1:].contiguous(), materialize=materialize)
     close(loss[0], fx[f"loss_S{S}"], rtol=1e-5, what="loss")
     grads = {}
     dx = AG.vocab_loss_bwd(dec, x, saved, grads)
