@@ -468,6 +468,114 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdArgs a) {
     }
 }
 
+// Short sequences (the caption decoder: T <= 50): one workgroup per (b,h) keeps Q, dO, K, V and the two T x T
+// matrices P and dS in LDS, so every operand is read from memory once and the three gradients leave in one pass.
+// Rows are padded to dk+16 floats: the 16-keys-by-4-parts score sweep then touches 64 distinct banks per 16 lanes.
+__global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dk = a.dk_, LD = dk + 16, Tq = a.Tq, Tk = a.Tk;
+    float* Qs = lds;
+    float* Os = Qs + Tq * LD;
+    float* Ks = Os + Tq * LD;
+    float* Vs = Ks + Tk * LD;
+    float* Ps = Vs + Tk * LD;          // [Tq][Tk] softmax probabilities
+    float* Ds = Ps + Tq * Tk;          // [Tq][Tk] dS = P * (dP - D)
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int nv = dk / 4;
+    for (int idx = threadIdx.x; idx < Tq * nv; idx += 256) {
+        const int r = idx / nv, c = idx - r * nv;
+        const int64_t row = (int64_t)b * Tq + r;
+        *reinterpret_cast<f32x4*>(&Qs[r * LD + 4 * c]) =
+            *reinterpret_cast<const f32x4*>(a.q + row * a.ldq + (int64_t)h * dk + 4 * c);
+        *reinterpret_cast<f32x4*>(&Os[r * LD + 4 * c]) =
+            *reinterpret_cast<const f32x4*>(a.dout + row * a.ldo + (int64_t)h * dk + 4 * c);
+    }
+    for (int idx = threadIdx.x; idx < Tk * nv; idx += 256) {
+        const int r = idx / nv, c = idx - r * nv;
+        *reinterpret_cast<f32x4*>(&Ks[r * LD + 4 * c]) =
+            *reinterpret_cast<const f32x4*>(a.k + (int64_t)b * a.sk + (int64_t)r * a.ldk + (int64_t)h * dk + 4 * c);
+        *reinterpret_cast<f32x4*>(&Vs[r * LD + 4 * c]) =
+            *reinterpret_cast<const f32x4*>(a.v + (int64_t)b * a.sv + (int64_t)r * a.ldv + (int64_t)h * dk + 4 * c);
+    }
+    __syncthreads();
+    const float scale = sqrtf((float)dk);
+    const int part = lane & 3, kl = lane >> 2, nm = dk / 16;
+    const int lpv = dk / 4, grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
+    // query rows: P, dS and dq
+    for (int i = wave; i < Tq; i += 4) {
+        const bool pad_row = a.ids && a.ids[(int64_t)b * a.ldid + i] == 0;
+        int nkeys = Tk;
+        if (a.causal && !pad_row) {
+            nkeys = i + a.causal_off + 1;
+            nkeys = nkeys < 1 ? 1 : (nkeys > Tk ? Tk : nkeys);
+        }
+        float* pi = Ps + i * Tk;
+        float* di = Ds + i * Tk;
+        if (pad_row) {
+            // uniform softmax over all keys, independent of q and k: dS = 0
+            for (int j = lane; j < Tk; j += 64) {
+                pi[j] = 1.0f / (float)Tk;
+                di[j] = 0.f;
+            }
+        } else {
+            f32x4 qreg[16], oreg[16];
+            load_parts(qreg, Qs + i * LD + 4 * part, nm);
+            load_parts(oreg, Os + i * LD + 4 * part, nm);
+            const float l = a.lse[((int64_t)b * a.H + h) * Tq + i];
+            float dacc = 0.f;
+            for (int j0 = 0; j0 < nkeys; j0 += 16) {
+                const int j = j0 + kl;
+                float sc = 0.f, dp = 0.f;
+                if (j < nkeys) {
+                    sc = dot_parts(qreg, Ks + j * LD + 4 * part, nm);
+                    dp = dot_parts(oreg, Vs + j * LD + 4 * part, nm);
+                }
+                sc = quad_sum(sc);
+                dp = quad_sum(dp);
+                if (j < nkeys && part == 0) {
+                    const float pr = expf(sc / scale - l);
+                    pi[j] = pr;
+                    di[j] = dp;
+                    dacc += pr * dp;
+                }
+            }
+            const float D = wave_sum(dacc);
+            // LDS serves one wavefront's accesses in order: the values written above are visible to its other lanes
+            for (int j = lane; j < Tk; j += 64) {
+                if (j < nkeys) di[j] = pi[j] * (di[j] - D);
+                else {
+                    pi[j] = 0.f;
+                    di[j] = 0.f;
+                }
+            }
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (!pad_row)
+            for (int j = grp; j < nkeys; j += ngrp)
+                acc += *reinterpret_cast<const f32x4*>(Ks + j * LD + 4 * dl) * (di[j] / scale);
+        group_reduce(acc, lpv);
+        if (grp == 0)
+            *reinterpret_cast<f32x4*>(a.dq + ((int64_t)b * Tq + i) * a.lddq + (int64_t)h * dk + 4 * dl) = acc;
+    }
+    __syncthreads();
+    // keys: dk_j = sum_i dS_ij q_i / sqrt(dk), dv_j = sum_i P_ij dO_i
+    for (int j = wave; j < Tk; j += 4) {
+        f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+        for (int i = grp; i < Tq; i += ngrp) {
+            const float pr = Ps[i * Tk + j], d = Ds[i * Tk + j];
+            av += *reinterpret_cast<const f32x4*>(Os + i * LD + 4 * dl) * pr;
+            ak += *reinterpret_cast<const f32x4*>(Qs + i * LD + 4 * dl) * (d / scale);
+        }
+        group_reduce(ak, lpv);
+        group_reduce(av, lpv);
+        if (grp == 0) {
+            *reinterpret_cast<f32x4*>(a.dk + (int64_t)b * a.sdk + (int64_t)j * a.lddk + (int64_t)h * dk + 4 * dl) = ak;
+            *reinterpret_cast<f32x4*>(a.dv + (int64_t)b * a.sdv + (int64_t)j * a.lddv + (int64_t)h * dk + 4 * dl) = av;
+        }
+    }
+}
+
 // ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) over one flat buffer -----------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
@@ -671,6 +779,12 @@ int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma
     return 0;
 }
 
+static int g_attn_bwd_two_pass = 0;
+int capdec_attention_bwd_force_two_pass(int on) {
+    g_attn_bwd_two_pass = on ? 1 : 0;
+    return 0;
+}
+
 int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
                          int64_t ldv, int64_t sv, const float* dout, int64_t ldo, const float* lse, float* dsum,
                          float* dq, int64_t lddq, float* dk, int64_t lddk, int64_t sdk, float* dv, int64_t lddv,
@@ -688,6 +802,16 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
     AttnBwdArgs a{q, ldq, k, ldk, sk, v, ldv, sv, dout, ldo, lse, dsum, dq, lddq, dk, lddk, sdk, dv, lddv, sdv,
                   B, H, Tq, Tk, dkh, causal, causal_off, ids, ldid};
     hipStream_t s = (hipStream_t)stream;
+    // short sequences: everything of one (b,h) fits in LDS
+    const size_t fused_lds = ((size_t)2 * (Tq + Tk) * (dkh + 16) + (size_t)2 * Tq * Tk) * sizeof(float);
+    if (Tq <= 64 && Tk <= 64 && fused_lds <= 144 * 1024 && !g_attn_bwd_two_pass) {
+        static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess;
+        if (!ready) return CAPDEC_EINVAL;
+        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3((unsigned)(B * H)), dim3(256), fused_lds, s, a);
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
     const long tq = (long)B * H * Tq, tk = (long)B * H * Tk;
     hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((tq + 3) / 4)), dim3(256), 4 * 2 * Tk * sizeof(float), s, a);
     CAPDEC_LAUNCH_CHECK();

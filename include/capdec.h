@@ -169,9 +169,9 @@ int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, con
                          void* stream);
 /* out[j] += sum_i x[i*ldx + j] */
 int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream);
-/* demb[ids[r],:] += dx[r,:]  (nn.Embedding backward, transformer.py:126 / cnnrnn_model.py:27) */
 /* out[g,:] = sum over t < T of x[g*T + t, :]  (gradient of a row that was broadcast over T positions) */
 int capdec_group_sum(const float* x, int G, int T, int E, float* out, void* stream);
+/* demb[ids[r],:] += dx[r,:]  (nn.Embedding backward, transformer.py:126 / cnnrnn_model.py:27) */
 int capdec_embed_bwd(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb, void* stream);
 int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma, const float* save_mean,
                              const float* save_rstd, int B, int C, float* dx, float* dgamma, float* dbeta,
@@ -184,6 +184,9 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
                          float* dq, int64_t lddq, float* dk, int64_t lddk, int64_t sdk, float* dv, int64_t lddv,
                          int64_t sdv, int B, int H, int Tq, int Tk, int dkh, int causal, int causal_off,
                          const int32_t* ids, int64_t ldid, void* stream);
+/* Test hook: sequences up to 64 positions normally take a one-pass kernel that keeps a (b,h) slice in LDS; on != 0
+ * forces the general two-pass kernels (any length up to 2048).  Process-wide; not for production use. */
+int capdec_attention_bwd_force_two_pass(int on);
 /* Materialised form of the same loss (train.py:216,254-256) for training, where the backward pass needs the
  * softmax anyway: logits [M,V] (row stride ld) are overwritten in place with d(mean NLL)/d(logits) =
  * (softmax - onehot(target)) / n_counted (zero rows for ignored targets).  sums must be zeroed by the caller:

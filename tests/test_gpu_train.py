@@ -288,3 +288,31 @@ def test_cnn_rnn_trainer_matches_oracle_training_loop():
             assert float(d.max()) <= 2.2 * 1e-3 * 3, (k, float(d.max()))
             if k != "batchnorm.running_mean":
                 assert float(d.mean()) <= 3e-6, (k, float(d.mean()))
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,dk,causal", [(5, 4, 20, 20, 128, True), (3, 2, 7, 5, 16, False), (2, 4, 50, 50, 128, True),
+                                                (4, 4, 20, 2, 64, False)])
+def test_attention_backward_one_pass_matches_two_pass(B, H, Tq, Tk, dk, causal):
+    """The LDS-resident backward for short sequences against the general two-pass kernels (both are also pinned by
+    the golden gradients through the decoder tests, which use short sequences)."""
+    from capdec import _lib, ops
+    g = torch.Generator().manual_seed(B * 100 + Tq)
+    E = H * dk
+    q, do = torch.randn(B * Tq, E, generator=g).cuda(), torch.randn(B * Tq, E, generator=g).cuda()
+    k, v = torch.randn(B * Tk, E, generator=g).cuda(), torch.randn(B * Tk, E, generator=g).cuda()
+    ids32 = None
+    if causal:
+        ids = torch.randint(1, 9, (B, Tq), generator=g)
+        ids[0, Tq // 2] = 0
+        ids[-1, -1] = 0
+        ids32 = ids.to(torch.int32).cuda()
+    _, lse = ops.attention(q, k, v, B, H, Tq, Tk, causal=causal, ids32=ids32, want_lse=True)
+    lib = _lib.load()
+    one = ops.attention_bwd(q, k, v, do, lse, B, H, Tq, Tk, causal=causal, ids32=ids32)
+    lib.capdec_attention_bwd_force_two_pass(1)
+    try:
+        two = ops.attention_bwd(q, k, v, do, lse, B, H, Tq, Tk, causal=causal, ids32=ids32)
+    finally:
+        lib.capdec_attention_bwd_force_two_pass(0)
+    for a, b, name in zip(one, two, ("dq", "dk", "dv")):
+        close(a, b.cpu().numpy(), rtol=1e-5, what=name)
