@@ -31,6 +31,28 @@ __global__ __launch_bounds__(256) void embed_pe_kernel(const IdT* __restrict__ i
 // ---- y = LayerNorm(x + add) * gamma + beta ------------------------------------------------------
 constexpr int LN_MAXV = 8;   // float4 per lane: E <= 2048
 
+// NV = float4 per lane (E <= 256 * NV): sized to the row so that the row's registers do not limit occupancy
+#define CAPDEC_LN_DISPATCH(E_, CALL)              \
+    do {                                           \
+        const int nvl_ = ((E_) / 4 + 63) / 64;     \
+        if (nvl_ <= 1) { CALL(1); }                \
+        else if (nvl_ <= 2) { CALL(2); }           \
+        else if (nvl_ <= 4) { CALL(4); }           \
+        else { CALL(8); }                          \
+    } while (0)
+// NM = head dimension / 16 (float4 per lane of the 4-lanes-per-key score sweep)
+#define CAPDEC_DK_DISPATCH(dk_, CALL)              \
+    do {                                           \
+        switch ((dk_) / 16) {                      \
+            case 1: CALL(1); break;                \
+            case 2: CALL(2); break;                \
+            case 4: CALL(4); break;                \
+            case 8: CALL(8); break;                \
+            default: CALL(16); break;              \
+        }                                          \
+    } while (0)
+
+template <int NV>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                             int add_div, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, int M, int E,
@@ -46,10 +68,10 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     // the addend's row: row / add_div, or (add_map[row] / add_div) when rows are listed explicitly
     const int arow = (add_map ? add_map[row] : row) / add_div;
     const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (int64_t)arow * E) : nullptr;
-    f32x4 v[LN_MAXV];
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
         v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < nv) {
@@ -61,7 +83,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     const float mean = wave_sum(s) / (float)E;
     float q = 0.f;
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
         if (c < nv) {
             v[u] -= mean;
@@ -74,7 +96,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
     const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
         if (c < nv) yr[c] = v[u] * rstd * g4[c] + b4[c];
     }
@@ -99,6 +121,7 @@ struct AttnArgs {
     const int32_t* rows_dev;                 // nullable device scalar: only rows r < rows_dev[0] are live
 };
 
+template <int NM>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -135,11 +158,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         // scores: 4 lanes per key, each lane owns dims {4*part + 16*m}
         const int part = lane & 3, kl = lane >> 2;
         const float* qp = a.q + qrow * a.ldq + (int64_t)h * dk + 4 * part;
-        const int nm = dk / 16;
-        f32x4 qreg[16];
+        f32x4 qreg[NM];
 #pragma unroll
-        for (int m = 0; m < 16; ++m)
-            qreg[m] = (m < nm) ? *reinterpret_cast<const f32x4*>(qp + 16 * m) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < NM; ++m) qreg[m] = *reinterpret_cast<const f32x4*>(qp + 16 * m);
         const float scale = sqrtf((float)dk);
         for (int j0 = 0; j0 < nkeys; j0 += 16) {
             const int j = j0 + kl;
@@ -147,11 +168,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
             if (j < nkeys) {
                 const float* kp = kb + (int64_t)j * a.ldk + 4 * part;
 #pragma unroll
-                for (int m = 0; m < 16; ++m)
-                    if (m < nm) {
-                        const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 16 * m);
-                        d += qreg[m][0] * kk[0] + qreg[m][1] * kk[1] + qreg[m][2] * kk[2] + qreg[m][3] * kk[3];
-                    }
+                for (int m = 0; m < NM; ++m) {
+                    const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 16 * m);
+                    d += qreg[m][0] * kk[0] + qreg[m][1] * kk[1] + qreg[m][2] * kk[2] + qreg[m][3] * kk[3];
+                }
             }
             d += __shfl_xor(d, 1, 64);
             d += __shfl_xor(d, 2, 64);
@@ -260,8 +280,11 @@ int capdec_launch_layernorm_rows(const float* x, const float* add, int add_div, 
                                  const float* gamma, const float* beta, float eps, int Mcap, int E, float* y,
                                  const int32_t* rows_dev, hipStream_t s) {
     if (Mcap == 0) return 0;
-    hipLaunchKernelGGL(add_layernorm_kernel, dim3((Mcap + 3) / 4), dim3(256), 0, s, x, add, add ? add_div : 1, gamma,
-                       beta, eps, Mcap, E, y, (float*)nullptr, (float*)nullptr, add_map, rows_dev);
+#define CAPDEC_CALL(NV_)                                                                                          \
+    hipLaunchKernelGGL(add_layernorm_kernel<NV_>, dim3((Mcap + 3) / 4), dim3(256), 0, s, x, add, add ? add_div : 1, \
+                       gamma, beta, eps, Mcap, E, y, (float*)nullptr, (float*)nullptr, add_map, rows_dev)
+    CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
+#undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -274,7 +297,10 @@ int capdec_launch_attention_rows(const float* q, int64_t ldq, const float* k, in
     AttnArgs a{q, ldq, k, ldk, sk, v, ldv, sv, out, ldo, Rcap, H, 1, Tk, dk, causal, 0, ids, ldid, nullptr,
                row_map, map_div, rows_dev};
     const long total = (long)Rcap * H;
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 4 * Tk * sizeof(float), s, a);
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attention_kernel<NM_>, dim3((unsigned)((total + 3) / 4)), dim3(256), 4 * Tk * sizeof(float), s, a)
+    CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
+#undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -318,9 +344,12 @@ int capdec_add_layernorm(const float* x, const float* add, int add_div, const fl
         (add && !capdec_aligned16(add)))
         return CAPDEC_EALIGN;
     if (M == 0) return 0;
-    hipLaunchKernelGGL(add_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add,
-                       add ? add_div : 1, gamma, beta, eps, M, E, y, mean, rstd, (const int32_t*)nullptr,
-                       (const int32_t*)nullptr);
+#define CAPDEC_CALL(NV_)                                                                                         \
+    hipLaunchKernelGGL(add_layernorm_kernel<NV_>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add,    \
+                       add ? add_div : 1, gamma, beta, eps, M, E, y, mean, rstd, (const int32_t*)nullptr,          \
+                       (const int32_t*)nullptr)
+    CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
+#undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -338,8 +367,11 @@ int capdec_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, i
     AttnArgs a{q, ldq, k, ldk, sk, v, ldv, sv, out, ldo, B, H, Tq, Tk, dk, causal, causal_off, ids, ldid, lse,
                nullptr, 1, nullptr};
     const long total = (long)B * H * Tq;
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 4 * Tk * sizeof(float),
-                       (hipStream_t)stream, a);
+#define CAPDEC_CALL(NM_)                                                                                          \
+    hipLaunchKernelGGL(attention_kernel<NM_>, dim3((unsigned)((total + 3) / 4)), dim3(256), 4 * Tk * sizeof(float), \
+                       (hipStream_t)stream, a)
+    CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
+#undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

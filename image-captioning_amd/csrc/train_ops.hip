@@ -45,6 +45,28 @@ __global__ void dropout4_kernel(const f32x4* __restrict__ x, int64_t n4, float p
 // ---- LayerNorm forward for training: s = add + dropout(x); y = LN(s) ---------------------------------
 constexpr int LN_MAXV = 8;
 
+// NV = float4 per lane (E <= 256 * NV): sized to the row so that the row's registers do not limit occupancy
+#define CAPDEC_LN_DISPATCH(E_, CALL)              \
+    do {                                           \
+        const int nvl_ = ((E_) / 4 + 63) / 64;     \
+        if (nvl_ <= 1) { CALL(1); }                \
+        else if (nvl_ <= 2) { CALL(2); }           \
+        else if (nvl_ <= 4) { CALL(4); }           \
+        else { CALL(8); }                          \
+    } while (0)
+// NM = head dimension / 16 (float4 per lane of the 4-lanes-per-key score sweep)
+#define CAPDEC_DK_DISPATCH(dk_, CALL)              \
+    do {                                           \
+        switch ((dk_) / 16) {                      \
+            case 1: CALL(1); break;                \
+            case 2: CALL(2); break;                \
+            case 4: CALL(4); break;                \
+            case 8: CALL(8); break;                \
+            default: CALL(16); break;              \
+        }                                          \
+    } while (0)
+
+template <int NV>
 __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int M, int E,
@@ -58,10 +80,10 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)(row / x_div) * E);
     const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (int64_t)row * E) : nullptr;
     const float inv_keep = 1.0f / (1.0f - p);
-    f32x4 v[LN_MAXV];
+    f32x4 v[NV];
     float sum = 0.f;
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
         v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < nv) {
@@ -77,14 +99,14 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
     if (s_out) {
         f32x4* sr = reinterpret_cast<f32x4*>(s_out + (int64_t)row * E);
 #pragma unroll
-        for (int u = 0; u < LN_MAXV; ++u) {
+        for (int u = 0; u < NV; ++u) {
             const int c = lane + 64 * u;
             if (c < nv) sr[c] = v[u];
         }
     }
     float q = 0.f;
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
         if (c < nv) {
             v[u] -= mean;
@@ -96,7 +118,7 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
     const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
         if (c < nv) yr[c] = v[u] * rstd * g4[c] + b4[c];
     }
@@ -111,6 +133,7 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
 // d_add = ds ; d_x = ds * dropout mask ; dgamma += sum_r dy * xhat ; dbeta += sum_r dy
 constexpr int LNB_ROWS = 32;   // rows per workgroup (8 per wavefront)
 
+template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int M, int E, float p,
@@ -121,9 +144,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const int nv = E / 4;
     const float inv_keep = 1.0f / (1.0f - p);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
-    f32x4 gam[LN_MAXV], ag[LN_MAXV], ab[LN_MAXV];
+    f32x4 gam[NV], ag[NV], ab[NV];
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
         gam[u] = c < nv ? g4[c] : f32x4{0.f, 0.f, 0.f, 0.f};
         ag[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -136,10 +159,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const f32x4* dyr = reinterpret_cast<const f32x4*>(dy + (int64_t)row * E);
         const f32x4* sr = reinterpret_cast<const f32x4*>(s + (int64_t)row * E);
         const float mu = mean[row], rs = rstd[row];
-        f32x4 g[LN_MAXV], xh[LN_MAXV];
+        f32x4 g[NV], xh[NV];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int u = 0; u < LN_MAXV; ++u) {
+        for (int u = 0; u < NV; ++u) {
             const int c = lane + 64 * u;
             g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             xh[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -156,7 +179,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         c1 = wave_sum(c1) / (float)E;
         c2 = wave_sum(c2) / (float)E;
 #pragma unroll
-        for (int u = 0; u < LN_MAXV; ++u) {
+        for (int u = 0; u < NV; ++u) {
             const int c = lane + 64 * u;
             if (c < nv) {
                 f32x4 ds = (g[u] - c1 - xh[u] * c2) * rs;
@@ -174,7 +197,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     float* pg = lds + (wave * 2 + 0) * E;
     float* pb = lds + (wave * 2 + 1) * E;
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
         if (c < nv) {
             reinterpret_cast<f32x4*>(pg)[c] = ag[u];
@@ -315,19 +338,20 @@ struct AttnBwdArgs {
     const int32_t* ids; int64_t ldid;
 };
 
-__device__ __forceinline__ float dot_parts(const f32x4 (&a)[16], const float* __restrict__ p, int nm) {
+template <int NM>
+__device__ __forceinline__ float dot_parts(const f32x4 (&a)[NM], const float* __restrict__ p) {
     float d = 0.f;
 #pragma unroll
-    for (int m = 0; m < 16; ++m)
-        if (m < nm) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p + 16 * m);
-            d += a[m][0] * b[0] + a[m][1] * b[1] + a[m][2] * b[2] + a[m][3] * b[3];
-        }
+    for (int m = 0; m < NM; ++m) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p + 16 * m);
+        d += a[m][0] * b[0] + a[m][1] * b[1] + a[m][2] * b[2] + a[m][3] * b[3];
+    }
     return d;
 }
-__device__ __forceinline__ void load_parts(f32x4 (&a)[16], const float* __restrict__ p, int nm) {
+template <int NM>
+__device__ __forceinline__ void load_parts(f32x4 (&a)[NM], const float* __restrict__ p) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) a[m] = (m < nm) ? *reinterpret_cast<const f32x4*>(p + 16 * m) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < NM; ++m) a[m] = *reinterpret_cast<const f32x4*>(p + 16 * m);
 }
 __device__ __forceinline__ float quad_sum(float d) {
     d += __shfl_xor(d, 1, 64);
@@ -344,6 +368,7 @@ __device__ __forceinline__ void group_reduce(f32x4& acc, int lpv) {
 }
 
 // query pass: one wavefront per (b,h,i): D_i and dq_i
+template <int NM>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -368,18 +393,18 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdArgs a) {
     float D = 0.f;
     if (!pad_row) {
         // 4 lanes per key, 16 keys per sweep step; q_i and dO_i stay in registers
-        const int part = lane & 3, kl = lane >> 2, nm = dk / 16;
-        f32x4 qreg[16], oreg[16];
-        load_parts(qreg, a.q + qoff * a.ldq + (int64_t)h * dk + 4 * part, nm);
-        load_parts(oreg, a.dout + qoff * a.ldo + (int64_t)h * dk + 4 * part, nm);
+        const int part = lane & 3, kl = lane >> 2;
+        f32x4 qreg[NM], oreg[NM];
+        load_parts(qreg, a.q + qoff * a.ldq + (int64_t)h * dk + 4 * part);
+        load_parts(oreg, a.dout + qoff * a.ldo + (int64_t)h * dk + 4 * part);
         const float l = a.lse[idx];
         float dacc = 0.f;
         for (int j0 = 0; j0 < nkeys; j0 += 16) {
             const int j = j0 + kl;
             float s = 0.f, dp = 0.f;
             if (j < nkeys) {
-                s = dot_parts(qreg, kb + (int64_t)j * a.ldk + 4 * part, nm);
-                dp = dot_parts(oreg, vb + (int64_t)j * a.ldv + 4 * part, nm);
+                s = dot_parts(qreg, kb + (int64_t)j * a.ldk + 4 * part);
+                dp = dot_parts(oreg, vb + (int64_t)j * a.ldv + 4 * part);
             }
             s = quad_sum(s);
             dp = quad_sum(dp);
@@ -405,6 +430,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnBwdArgs a) {
 }
 
 // key pass: one wavefront per (b,h,j): dk_j and dv_j
+template <int NM>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -417,12 +443,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdArgs a) {
     float* dd = pp + a.Tq;                 // ds_ij
     const int dk = a.dk_;
     const float scale = sqrtf((float)dk);
-    const int part = lane & 3, il = lane >> 2, nm = dk / 16;
+    const int part = lane & 3, il = lane >> 2;
     const float* kj = a.k + (int64_t)b * a.sk + (int64_t)j * a.ldk + (int64_t)h * dk;
     const float* vj = a.v + (int64_t)b * a.sv + (int64_t)j * a.ldv + (int64_t)h * dk;
-    f32x4 kreg[16], vreg[16];
-    load_parts(kreg, kj + 4 * part, nm);
-    load_parts(vreg, vj + 4 * part, nm);
+    f32x4 kreg[NM], vreg[NM];
+    load_parts(kreg, kj + 4 * part);
+    load_parts(vreg, vj + 4 * part);
     for (int i0 = 0; i0 < a.Tq; i0 += 16) {
         const int i = i0 + il;
         float s = 0.f, dp = 0.f;
@@ -432,8 +458,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdArgs a) {
             seen = pad_row || !a.causal || (j <= i + a.causal_off);
             if (seen && !pad_row) {
                 const int64_t qoff = (int64_t)b * a.Tq + i;
-                s = dot_parts(kreg, a.q + qoff * a.ldq + (int64_t)h * dk + 4 * part, nm);
-                dp = dot_parts(vreg, a.dout + qoff * a.ldo + (int64_t)h * dk + 4 * part, nm);
+                s = dot_parts(kreg, a.q + qoff * a.ldq + (int64_t)h * dk + 4 * part);
+                dp = dot_parts(vreg, a.dout + qoff * a.ldo + (int64_t)h * dk + 4 * part);
             }
         }
         s = quad_sum(s);
@@ -471,6 +497,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnBwdArgs a) {
 // Short sequences (the caption decoder: T <= 50): one workgroup per (b,h) keeps Q, dO, K, V and the two T x T
 // matrices P and dS in LDS, so every operand is read from memory once and the three gradients leave in one pass.
 // Rows are padded to dk+16 floats: the 16-keys-by-4-parts score sweep then touches 64 distinct banks per 16 lanes.
+template <int NM>
 __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -500,7 +527,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
     }
     __syncthreads();
     const float scale = sqrtf((float)dk);
-    const int part = lane & 3, kl = lane >> 2, nm = dk / 16;
+    const int part = lane & 3, kl = lane >> 2;
     const int lpv = dk / 4, grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
     // query rows: P, dS and dq
     for (int i = wave; i < Tq; i += 4) {
@@ -519,17 +546,17 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
                 di[j] = 0.f;
             }
         } else {
-            f32x4 qreg[16], oreg[16];
-            load_parts(qreg, Qs + i * LD + 4 * part, nm);
-            load_parts(oreg, Os + i * LD + 4 * part, nm);
+            f32x4 qreg[NM], oreg[NM];
+            load_parts(qreg, Qs + i * LD + 4 * part);
+            load_parts(oreg, Os + i * LD + 4 * part);
             const float l = a.lse[((int64_t)b * a.H + h) * Tq + i];
             float dacc = 0.f;
             for (int j0 = 0; j0 < nkeys; j0 += 16) {
                 const int j = j0 + kl;
                 float sc = 0.f, dp = 0.f;
                 if (j < nkeys) {
-                    sc = dot_parts(qreg, Ks + j * LD + 4 * part, nm);
-                    dp = dot_parts(oreg, Vs + j * LD + 4 * part, nm);
+                    sc = dot_parts(qreg, Ks + j * LD + 4 * part);
+                    dp = dot_parts(oreg, Vs + j * LD + 4 * part);
                 }
                 sc = quad_sum(sc);
                 dp = quad_sum(dp);
@@ -719,8 +746,11 @@ int capdec_add_layernorm_train(const float* x, int x_div, const float* add, cons
         (add && !capdec_aligned16(add)) || (s_out && !capdec_aligned16(s_out)))
         return CAPDEC_EALIGN;
     if (M == 0) return 0;
-    hipLaunchKernelGGL(ln_train_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, gamma, beta,
-                       eps, M, E, x_div, p, seed, y, s_out, mean, rstd);
+#define CAPDEC_CALL(NV_)                                                                                          \
+    hipLaunchKernelGGL(ln_train_fwd_kernel<NV_>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, gamma, \
+                       beta, eps, M, E, x_div, p, seed, y, s_out, mean, rstd)
+    CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
+#undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -734,8 +764,11 @@ int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, con
         (d_x && !capdec_aligned16(d_x)))
         return CAPDEC_EALIGN;
     if (M == 0) return 0;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 8 * E * sizeof(float),
-                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, d_add, d_x, dgamma, dbeta);
+#define CAPDEC_CALL(NV_)                                                                                           \
+    hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 8 * E * sizeof(float),     \
+                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, d_add, d_x, dgamma, dbeta)
+    CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
+#undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -805,17 +838,33 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
     // short sequences: everything of one (b,h) fits in LDS
     const size_t fused_lds = ((size_t)2 * (Tq + Tk) * (dkh + 16) + (size_t)2 * Tq * Tk) * sizeof(float);
     if (Tq <= 64 && Tk <= 64 && fused_lds <= 144 * 1024 && !g_attn_bwd_two_pass) {
-        static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess;
+        static const bool ready = [] {
+            bool ok = true;
+#define CAPDEC_CALL(NM_)                                                                                    \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NM_>),               \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess
+            CAPDEC_CALL(1); CAPDEC_CALL(2); CAPDEC_CALL(4); CAPDEC_CALL(8); CAPDEC_CALL(16);
+#undef CAPDEC_CALL
+            return ok;
+        }();
         if (!ready) return CAPDEC_EINVAL;
-        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3((unsigned)(B * H)), dim3(256), fused_lds, s, a);
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), fused_lds, s, a)
+        CAPDEC_DK_DISPATCH(dkh, CAPDEC_CALL);
+#undef CAPDEC_CALL
         CAPDEC_LAUNCH_CHECK();
         return 0;
     }
     const long tq = (long)B * H * Tq, tk = (long)B * H * Tk;
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((tq + 3) / 4)), dim3(256), 4 * 2 * Tk * sizeof(float), s, a);
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attn_bwd_q_kernel<NM_>, dim3((unsigned)((tq + 3) / 4)), dim3(256), 4 * 2 * Tk * sizeof(float), s, a)
+    CAPDEC_DK_DISPATCH(dkh, CAPDEC_CALL);
+#undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((tk + 3) / 4)), dim3(256), 4 * 2 * Tq * sizeof(float), s, a);
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<NM_>, dim3((unsigned)((tk + 3) / 4)), dim3(256), 4 * 2 * Tq * sizeof(float), s, a)
+    CAPDEC_DK_DISPATCH(dkh, CAPDEC_CALL);
+#undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
