@@ -231,38 +231,62 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 
 // train: batch statistics per column (two passes: mean, then centred variance), normalise, and update
 // the running buffers (biased variance normalises, unbiased variance feeds the running average).
-// 64 columns per workgroup; lane = column, the 4 wavefronts stride the rows.
+// The batch is small (a few hundred rows), so the kernel is latency-bound: 16 columns per workgroup,
+// 16 threads per column striding the rows, four independent loads in flight per thread.
+constexpr int BN_CW = 16, BN_RG = 16;
+
+__device__ __forceinline__ float bn_col_reduce(float v, float (*red)[BN_CW], int rg, int cl) {
+    __syncthreads();                 // previous use of red is over
+    red[rg][cl] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < BN_RG; ++g) t += red[g][cl];
+    return t;
+}
+
 __global__ __launch_bounds__(256) void bn_train_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, float momentum,
                                                        float* __restrict__ running_mean,
                                                        float* __restrict__ running_var, int B, int C,
                                                        float* __restrict__ y, float* __restrict__ save_mean,
                                                        float* __restrict__ save_rstd) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    __shared__ float red[BN_RG][BN_CW];
+    const int cl = threadIdx.x & (BN_CW - 1), rg = threadIdx.x / BN_CW;
+    const int c = blockIdx.x * BN_CW + cl;
     const bool ok = c < C;
-    float s = 0.f;
-    if (ok)
-        for (int r = wave; r < B; r += 4) s += x[(int64_t)r * C + c];
-    red[wave][lane] = s;
-    __syncthreads();
-    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)B;
-    __syncthreads();
-    float q = 0.f;
-    if (ok)
-        for (int r = wave; r < B; r += 4) {
-            const float d = x[(int64_t)r * C + c] - mean;
-            q += d * d;
+    const float* xc = x + (ok ? c : 0);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (ok) {
+        int r = rg;
+        for (; r + 3 * BN_RG < B; r += 4 * BN_RG) {
+            s0 += xc[(int64_t)r * C];
+            s1 += xc[(int64_t)(r + BN_RG) * C];
+            s2 += xc[(int64_t)(r + 2 * BN_RG) * C];
+            s3 += xc[(int64_t)(r + 3 * BN_RG) * C];
         }
-    red[wave][lane] = q;
-    __syncthreads();
-    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)B;
+        for (; r < B; r += BN_RG) s0 += xc[(int64_t)r * C];
+    }
+    const float mean = bn_col_reduce((s0 + s1) + (s2 + s3), red, rg, cl) / (float)B;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+    if (ok) {
+        int r = rg;
+        for (; r + 3 * BN_RG < B; r += 4 * BN_RG) {
+            const float d0 = xc[(int64_t)r * C] - mean, d1 = xc[(int64_t)(r + BN_RG) * C] - mean;
+            const float d2 = xc[(int64_t)(r + 2 * BN_RG) * C] - mean, d3 = xc[(int64_t)(r + 3 * BN_RG) * C] - mean;
+            q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
+        }
+        for (; r < B; r += BN_RG) {
+            const float d = xc[(int64_t)r * C] - mean;
+            q0 += d * d;
+        }
+    }
+    const float var = bn_col_reduce((q0 + q1) + (q2 + q3), red, rg, cl) / (float)B;
     const float rstd = 1.0f / sqrtf(var + eps);
     if (!ok) return;
     const float g = gamma[c], bt = beta[c];
-    for (int r = wave; r < B; r += 4) y[(int64_t)r * C + c] = (x[(int64_t)r * C + c] - mean) * rstd * g + bt;
-    if (wave == 0) {
+    for (int r = rg; r < B; r += BN_RG) y[(int64_t)r * C + c] = (xc[(int64_t)r * C] - mean) * rstd * g + bt;
+    if (rg == 0) {
         if (save_mean) save_mean[c] = mean;
         if (save_rstd) save_rstd[c] = rstd;
         if (running_mean) {
@@ -390,7 +414,7 @@ int capdec_bn_train_forward(const float* x, const float* gamma, const float* bet
                             float* save_rstd, void* stream) {
     CAPDEC_REQUIRE(x && gamma && beta && y && B >= 2 && C >= 1);
     CAPDEC_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
-    hipLaunchKernelGGL(bn_train_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_train_kernel, dim3((C + BN_CW - 1) / BN_CW), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
                        momentum, running_mean, running_var, B, C, y, save_mean, save_rstd);
     CAPDEC_LAUNCH_CHECK();
     return 0;

@@ -218,26 +218,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // ---- column sums: out[j] += sum_i x[i*ldx + j]  (bias gradients) -------------------------------------
-// A workgroup sums CS_ROWS rows of a 256-column strip: 64 lanes x 16 B per row, four rows in flight per
-// wavefront (independent accumulators), one atomic per column and workgroup.
-constexpr int CS_ROWS = 128;
+// A workgroup sums CS_ROWS rows of a 64-column strip: 16 lanes x 16 B per row and 16 row groups, eight
+// independent rows in flight per thread, one atomic per column and workgroup.  Same-address float atomics
+// serialise (about 50 ns each), so the strip is kept narrow and tall: few partial sums per column.
+constexpr int CS_ROWS = 256;
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
                                                      float* __restrict__ out) {
-    __shared__ f32x4 red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 256 + lane * 4;
+    __shared__ f32x4 red[16][16];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j = blockIdx.x * 64 + cl * 4;
     const int r0 = blockIdx.y * CS_ROWS;
     const int r1 = min(M, r0 + CS_ROWS);
-    f32x4 s[4];
+    f32x4 s[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (j < N) {
-        for (int r = r0 + wave; r < r1; r += 16) {
+        for (int r = r0 + rg; r < r1; r += 128) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int rr = r + 4 * u;
+            for (int u = 0; u < 8; ++u) {
+                const int rr = r + 16 * u;
                 if (rr < r1) {
                     const float* p = x + (int64_t)rr * ldx + j;
                     if (VEC) s[u] += *reinterpret_cast<const f32x4*>(p);
@@ -249,10 +250,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
             }
         }
     }
-    red[wave][lane] = (s[0] + s[1]) + (s[2] + s[3]);
+    red[rg][cl] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
-    if (wave == 0 && j < N) {
-        const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (rg == 0 && j < N) {
+        f32x4 t = red[0][cl];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += red[g][cl];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (j + c < N) atomicAdd(&out[j + c], t[c]);
@@ -274,49 +277,85 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict_
 }
 
 // ---- embedding backward: demb[ids[r], :] += dx[r, :] ----------------------------------------------
+// Same-address float atomics serialise, and a few ids are very frequent: the reference's vocabulary reserves
+// ids 0..3 for <PAD>/<SOS>/<EOS>/<UNK> (get_loader.py:28-29), <SOS> opens every caption and <PAD> fills the
+// tail of most.  Rows with an id below EB_HOT are therefore summed per workgroup in LDS first and leave as one
+// atomic per column; every other row goes straight to memory.  (Purely a speed heuristic: any ids are correct.)
+constexpr int EB_HOT = 4, EB_ROWS = 64;
+
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
                                                         int rows, int E, int V, float* __restrict__ demb) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    long id = ids[row];
-    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    const float* src = dx + (int64_t)row * E;
-    float* dst = demb + id * (int64_t)E;
-    for (int c = lane; c < E; c += 64) atomicAdd(&dst[c], src[c]);
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [EB_HOT][E]
+    __shared__ int used[EB_HOT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = threadIdx.x; c < EB_HOT * E; c += 256) lds[c] = 0.f;
+    if (threadIdx.x < EB_HOT) used[threadIdx.x] = 0;
+    __syncthreads();
+    for (int rr = wave; rr < EB_ROWS; rr += 4) {
+        const int row = blockIdx.x * EB_ROWS + rr;
+        if (row >= rows) break;
+        long id = ids[row];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        const float* src = dx + (int64_t)row * E;
+        if (id < EB_HOT) {
+            if (lane == 0) used[id] = 1;
+            for (int c = lane; c < E; c += 64) atomicAdd(&lds[id * E + c], src[c]);
+        } else {
+            float* dst = demb + id * (int64_t)E;
+            for (int c = lane; c < E; c += 64) atomicAdd(&dst[c], src[c]);
+        }
+    }
+    __syncthreads();
+    for (int hgt = 0; hgt < EB_HOT && hgt < V; ++hgt)
+        if (used[hgt])
+            for (int c = threadIdx.x; c < E; c += 256) atomicAdd(&demb[(int64_t)hgt * E + c], lds[hgt * E + c]);
 }
 
 // ---- BatchNorm1d backward (training statistics) ------------------------------------------------------
+// Same shape as the forward: 16 columns per workgroup, 16 threads per column striding the rows.
+constexpr int BN_CW = 16, BN_RG = 16;
+
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int B, int C,
                                                      float* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta) {
-    __shared__ float red[2][4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    __shared__ float red[2][BN_RG][BN_CW];
+    const int cl = threadIdx.x & (BN_CW - 1), rg = threadIdx.x / BN_CW;
+    const int c = blockIdx.x * BN_CW + cl;
     const bool ok = c < C;
     const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    if (ok)
-        for (int r = wave; r < B; r += 4) {
-            const float d = dy[(int64_t)r * C + c];
-            s1 += d;
-            s2 += d * (x[(int64_t)r * C + c] - mu) * rs;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    if (ok) {
+        int r = rg;
+        for (; r + BN_RG < B; r += 2 * BN_RG) {
+            const float d0 = dy[(int64_t)r * C + c], d1 = dy[(int64_t)(r + BN_RG) * C + c];
+            const float x0 = x[(int64_t)r * C + c], x1 = x[(int64_t)(r + BN_RG) * C + c];
+            a0 += d0; a1 += d1;
+            b0 += d0 * (x0 - mu) * rs; b1 += d1 * (x1 - mu) * rs;
         }
-    red[0][wave][lane] = s1;
-    red[1][wave][lane] = s2;
+        for (; r < B; r += BN_RG) {
+            const float d = dy[(int64_t)r * C + c];
+            a0 += d;
+            b0 += d * (x[(int64_t)r * C + c] - mu) * rs;
+        }
+    }
+    red[0][rg][cl] = a0 + a1;
+    red[1][rg][cl] = b0 + b1;
     __syncthreads();
-    s1 = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-    s2 = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < BN_RG; ++g) {
+        s1 += red[0][g][cl];
+        s2 += red[1][g][cl];
+    }
     if (!ok) return;
-    const float g = gamma[c];
-    const float k = g * rs;
-    for (int r = wave; r < B; r += 4) {
+    const float k = gamma[c] * rs;
+    for (int r = rg; r < B; r += BN_RG) {
         const float xh = (x[(int64_t)r * C + c] - mu) * rs;
         dx[(int64_t)r * C + c] = k * (dy[(int64_t)r * C + c] - s1 / (float)B - xh * s2 / (float)B);
     }
-    if (wave == 0) {
+    if (rg == 0) {
         dgamma[c] += s2;
         dbeta[c] += s1;
     }
@@ -631,20 +670,18 @@ inline int grid_for(int64_t n) {
 }
 
 // ---- materialised vocabulary loss: logits [M,V] -> d(mean NLL)/d(logits) in place ---------------------
-// count_targets: sums[1] = number of counted targets, gscale[0] = 1 / that number
+// count_targets: sums[1] += number of counted targets (sums zeroed by the caller; integer-valued float adds are exact)
 __global__ __launch_bounds__(256) void count_targets_kernel(const int64_t* __restrict__ targets, int M,
-                                                            int64_t ignore_index, float* __restrict__ sums,
-                                                            float* __restrict__ gscale) {
+                                                            int64_t ignore_index, float* __restrict__ sums) {
     __shared__ int red[4];
     int c = 0;
-    for (int i = threadIdx.x; i < M; i += 256) c += targets[i] != ignore_index ? 1 : 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) c += targets[i] != ignore_index ? 1 : 0;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float n = (float)(red[0] + red[1] + red[2] + red[3]);
-        sums[1] = n;
-        gscale[0] = 1.0f / n;
+        const int n = red[0] + red[1] + red[2] + red[3];
+        if (n) atomicAdd(&sums[1], (float)n);
     }
 }
 
@@ -657,11 +694,12 @@ constexpr int SM_ROWS = 16;
 template <bool VEC>
 __global__ __launch_bounds__(256) void softmax_nll_grad_kernel(float* __restrict__ logits, int64_t ld,
                                                                const int64_t* __restrict__ targets, int M, int V,
-                                                               int64_t ignore_index, const float* __restrict__ gscale,
+                                                               int64_t ignore_index, float* __restrict__ gscale,
                                                                float* __restrict__ sums, float* __restrict__ lse_out) {
     __shared__ float red[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float gs = gscale[0];
+    const float gs = 1.0f / sums[1];            // complete: the counting kernel ran before this one
+    if (blockIdx.x == 0 && threadIdx.x == 0) gscale[0] = gs;
     float acc = 0.f;
     for (int rr = wave; rr < SM_ROWS; rr += 4) {
         const int row = blockIdx.x * SM_ROWS + rr;
@@ -777,7 +815,7 @@ int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* s
     CAPDEC_REQUIRE(x && out && M >= 0 && N >= 1 && ldx >= N);
     if (M == 0) return 0;
     const bool vec = N % 4 == 0 && ldx % 4 == 0 && capdec_aligned16(x);
-    dim3 grid((N + 255) / 256, (M + CS_ROWS - 1) / CS_ROWS);
+    dim3 grid((N + 63) / 64, (M + CS_ROWS - 1) / CS_ROWS);
     if (vec) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, out);
     else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, out);
     CAPDEC_LAUNCH_CHECK();
@@ -796,8 +834,9 @@ int capdec_group_sum(const float* x, int G, int T, int E, float* out, void* stre
 int capdec_embed_bwd(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb, void* stream) {
     CAPDEC_REQUIRE(ids && dx && demb && rows >= 0 && E >= 1 && V >= 1);
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, dx, rows, E, V,
-                       demb);
+    CAPDEC_REQUIRE((size_t)EB_HOT * E * sizeof(float) <= 60 * 1024);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + EB_ROWS - 1) / EB_ROWS), dim3(256), EB_HOT * E * sizeof(float),
+                       (hipStream_t)stream, ids, dx, rows, E, V, demb);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -806,7 +845,7 @@ int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma
                              const float* save_rstd, int B, int C, float* dx, float* dgamma, float* dbeta,
                              void* stream) {
     CAPDEC_REQUIRE(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && B >= 1 && C >= 1);
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, save_mean,
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3((C + BN_CW - 1) / BN_CW), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, save_mean,
                        save_rstd, B, C, dx, dgamma, dbeta);
     CAPDEC_LAUNCH_CHECK();
     return 0;
@@ -873,8 +912,9 @@ int capdec_softmax_nll_grad(float* logits, int64_t ld, const int64_t* targets, i
                             float* sums, float* gscale, float* lse_out, void* stream) {
     CAPDEC_REQUIRE(logits && targets && sums && gscale && M >= 0 && V >= 1 && ld >= V);
     if (M == 0) return 0;
-    hipLaunchKernelGGL(count_targets_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, targets, M, ignore_index, sums,
-                       gscale);
+    const int count_grid = M >= 16 * 256 ? 16 : (M + 255) / 256;
+    hipLaunchKernelGGL(count_targets_kernel, dim3(count_grid), dim3(256), 0, (hipStream_t)stream, targets, M, ignore_index,
+                       sums);
     const bool vec = V % 4 == 0 && ld % 4 == 0 && capdec_aligned16(logits);
     const dim3 grid((M + SM_ROWS - 1) / SM_ROWS);
     if (vec)
