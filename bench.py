@@ -62,7 +62,7 @@ def cpu_baseline(target_seconds=12.0):
                       f"{dt:.1f} s on {threads} torch CPU threads"}
 
 
-def train_bench(device, rank, world, steps, warmup, fence):
+def train_bench(device, rank, world, steps, warmup, fence, note=lambda m: None):
     """BASELINE.json configs[2]: ViT-Attn teacher-forced training, B=512 per GPU (the reference's DDP draws a full
     batch per rank), T=20, E=512, H=4, L=3, V=10000, features [512,1000] -> one memory row (reference-faithful).
     One step = head + decoder forward, fused CE loss, backward, RCCL gradient all-reduce, Adam."""
@@ -71,7 +71,8 @@ def train_bench(device, rank, world, steps, warmup, fence):
     Bt, T, Lt = 512, 20, 3
     torch.manual_seed(0)
     model = VITAttentionModel(E, V, H, Lt).to(device)
-    tr = CaptionTrainer(model, lr=1e-3)
+    tr = CaptionTrainer(model, lr=1e-3, overlap=os.environ.get("CAPDEC_TRAIN_OVERLAP", "1") == "1")
+    note("trainer built")
     g = torch.Generator().manual_seed(1234 + 3 + 1000 * rank)
     feats = torch.rand(Bt, 1000, generator=g).to(device)
     caps = torch.zeros(Bt, T + 1, dtype=torch.long)
@@ -84,7 +85,9 @@ def train_bench(device, rank, world, steps, warmup, fence):
     first = None
     for _ in range(warmup):
         loss = tr.step(feats, caps)
+        note("train step enqueued")
         first = first if first is not None else float(loss.item())
+        note("train warmup step done")
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -116,6 +119,7 @@ def main():
     ap.add_argument("--grid", type=int, default=1, help="memory rows S (1 = reference-faithful pooled feature)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=10, help="timed training steps of cfg3 (0 = skip)")
+    ap.add_argument("--train-budget", type=float, default=240.0, help="seconds after which the training leg is abandoned")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,15 +127,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    device = torch.device("cuda", local_rank)
+    # CAPDEC_BENCH_REHEARSAL=1: several ranks share GPU 0 over gloo (RCCL refuses two ranks on one device); only for
+    # rehearsing the multi-rank control flow on a one-GPU box, never for reported numbers
+    rehearsal = os.environ.get("CAPDEC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("CAPDEC_REHEARSAL_DUMP_S", "40")), exit=False)     # where is a stuck rank?
+    device = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    def note(msg):
+        if rehearsal:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     from capdec import _lib, engine, ops
     _lib.load()
     model = build_model(device)
+    note("model built")
     S = args.grid
     g = torch.Generator().manual_seed(1234 + 2 + 1000 * rank)
     if S == 1:
@@ -147,8 +165,11 @@ def main():
                                                       to_cpu=False)
             if world > 1:
                 # batch-sharded decode: the only exchange is the final gather of the token ids
-                all_ids = torch.empty((world * B, LEN), dtype=torch.int64, device=device) if rank == 0 else None
-                all_len = torch.empty((world * B,), dtype=torch.int32, device=device) if rank == 0 else None
+                if rehearsal:                       # gloo gathers host tensors only
+                    ids, lens = ids.cpu(), lens.cpu()
+                gdev = ids.device
+                all_ids = torch.empty((world * B, LEN), dtype=torch.int64, device=gdev) if rank == 0 else None
+                all_len = torch.empty((world * B,), dtype=torch.int32, device=gdev) if rank == 0 else None
                 dist.gather(ids, list(all_ids.chunk(world)) if rank == 0 else None, dst=0)
                 dist.gather(lens, list(all_len.chunk(world)) if rank == 0 else None, dst=0)
                 if rank == 0:
@@ -165,7 +186,9 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+        note("warmup step done")
     fence()
+    note("fence passed")
     t0 = time.perf_counter()
     vocab_ms, dirty_rows = [], 0
     for _ in range(args.steps):
@@ -180,12 +203,18 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    train = None
-    if args.train_steps > 0:
-        del model
-        train = train_bench(device, rank, world, args.train_steps, 3, fence)
-
+    note("decode timed")
+    out = None
     if rank == 0:
+        # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the figure is
+        # read from the committed summary of the same command (profiles/vocab_traffic.json: FETCH_SIZE doubled per the
+        # gfx950 correction + WRITE_SIZE, KiB -> bytes, averaged per launch); null when the file is absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "vocab_traffic.json")) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch") if S == 1 else None
+        except (OSError, ValueError):
+            traffic = None
         captions = world * B * args.steps
         avg_ms = sum(vocab_ms) / len(vocab_ms)
         flops = 2.0 * B * E * V                      # algorithmic FLOPs of one vocabulary projection launch
@@ -201,10 +230,36 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "vocab_reduce_kernel (fc2 projection + fused arg-max)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "avg_launch_ms": avg_ms,
-                         "launches_timed": len(vocab_ms), "traffic": None},
+                         "launches_timed": len(vocab_ms), "traffic": traffic,
+                         "algorithmic_bytes": 4.0 * (V * E + B * E + V) + 8.0 * B * ((V + 127) // 128)},
         }
-        if train is not None:
+
+    # The training leg must never cost the decode result: if it has not finished within its budget (a wedged
+    # collective cannot be cancelled), rank 0 still prints the line, with the reason in place of the numbers.
+    import threading
+    done = threading.Event()
+
+    def give_up():
+        if done.is_set():
+            return
+        if rank == 0:
+            out["train"] = {"error": f"training leg did not finish within {args.train_budget} s"}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    if args.train_steps > 0:
+        watchdog = threading.Timer(args.train_budget, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        del model
+        train = train_bench(device, rank, world, args.train_steps, args.warmup, fence, note)
+        done.set()
+        watchdog.cancel()
+        note("train timed")
+        if rank == 0:
             out["train"] = train
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -32,8 +32,11 @@ def _head_spec(model):
 class CaptionTrainer:
     """One object per process (one process per GPU)."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, pad_idx=0):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, pad_idx=0, overlap=True):
+        """overlap=True: one async all-reduce per gradient segment, issued as soon as the backward pass has enqueued
+        that segment; overlap=False: a single all-reduce of the whole flat gradient buffer after the backward pass."""
         self.model = model
+        self.overlap = overlap
         self.lr, self.betas, self.eps, self.pad_idx = lr, betas, eps, pad_idx
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -85,7 +88,7 @@ class CaptionTrainer:
 
     # -----------------------------------------------------------------------------------------
     def _reduce_segment(self, i, works):
-        if self.world > 1:
+        if self.world > 1 and self.overlap:
             a, b = self.segments[i]
             works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -102,6 +105,8 @@ class CaptionTrainer:
             loss = self._rnn_step(feats, ids, tgt)
         else:
             loss = self._tf_step(feats, ids, tgt)
+        if self.world > 1 and not self.overlap:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
         # ---- Adam over the flat buffers (DDP semantics: mean of the per-rank gradients) ----
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1],
                       self.eps, grad_scale=1.0 / self.world)
