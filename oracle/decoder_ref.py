@@ -247,6 +247,19 @@ def decoder_rnn_forward(sd: SD, feats: torch.Tensor, ids: torch.Tensor, training
     return (logits, new) if with_buffers else logits
 
 
+def cnnrnn_logits_after(sd: SD, feats: torch.Tensor, prefix: List[int], sos: int = SOS) -> torch.Tensor:
+    """Logits [B,V] of the greedy loop (cnnrnn_model.py:77-87) after feeding <SOS> and then ``prefix`` (the same
+    tokens for every row): what the reference ranks when it picks token number len(prefix)."""
+    B = feats.shape[0]
+    h, c, _ = rnn_image_state(sd, feats, False)
+    out = None
+    for tok in [sos] + list(prefix):
+        emb = sd["embed.weight"][torch.full((B,), int(tok), dtype=torch.long)]
+        h, c = lstm_cell(emb, h, c, *_lstm_w(sd))
+        out = linear(h, sd["fc2.weight"], sd["fc2.bias"])
+    return out
+
+
 def cnnrnn_greedy_ids(sd: SD, feats: torch.Tensor, max_length: int, sos: int = SOS, eos: int = EOS) -> List[List[int]]:
     """``CNNtoRNN.caption_images`` up to detokenisation (cnnrnn_model.py:57-106)."""
     B = feats.shape[0]

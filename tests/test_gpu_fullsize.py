@@ -1,0 +1,157 @@
+"""GPU parity at the full sizes of the benchmark configurations (all five), through the drop-in classes.
+
+The oracle cannot run the full batches in seconds, so each test checks (i) a row subset or a reduced quantity
+against the oracle on the same inputs and (ii) size-independent properties (rows are independent: a sub-batch
+decoded alone gives the same ids; the loss of the full batch equals the oracle's loss on the full batch, which is
+cheap because only one forward pass is needed).  Tolerances as everywhere: 1e-4 relative; greedy ids identical
+up to near-ties of the oracle's top-2 logits."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import REL, check_greedy, close, cpu_sd
+from oracle import decoder_ref as R
+
+pytestmark = pytest.mark.gpu
+
+E, H, V = 512, 4, 10000
+
+
+def _captions(g, B, T, V):
+    caps = torch.zeros(B, T + 1, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(8, T, (1,), generator=g))
+        caps[b, 0] = 1
+        caps[b, 1:1 + n] = torch.randint(4, V, (n,), generator=g)
+        caps[b, 1 + n] = 2
+    return caps
+
+
+def _rows(ids, lengths):
+    from capdec.engine import ids_to_lists
+    return ids_to_lists(ids, lengths)
+
+
+def test_cfg1_cnn_rnn_greedy_b32_len20():
+    """BASELINE configs[0]: CNN-RNN greedy, B=32, E=256, hidden 512, V=5000, length 20, against the oracle on the
+    whole batch (it is small enough)."""
+    from models.cnnrnn_model import CNNtoRNN
+    torch.manual_seed(0)
+    m = CNNtoRNN(256, 512, 5000)
+    sd = {k[len("decoderRNN."):]: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1234 + 1)
+    feats = torch.rand(32, 2048, generator=g)
+    m = m.cuda()
+    got = _rows(*m.caption_ids(feats.cuda(), max_length=20))
+    want = R.cnnrnn_greedy_ids(sd, feats, 20)
+    assert len(got) == 32
+    for b, (gr, wr) in enumerate(zip(got, want)):
+        if gr == wr:
+            continue
+        n = min(len(gr), len(wr))
+        s = next((i for i in range(n) if gr[i] != wr[i]), n)
+        logits = R.cnnrnn_logits_after(sd, feats[b:b + 1], wr[:s])[0]
+        tok = gr[s] if s < len(gr) else R.EOS
+        gap = float(logits.max() - logits[tok])
+        assert gap <= REL * float(logits.abs().max()), f"row {b} step {s}: logit gap {gap:.3e}"
+
+
+def _oracle_grads(sd0, head, feats, caps, check, dtype):
+    sd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()).requires_grad_(k in check)
+          for k, v in sd0.items()}
+    enc, _ = head(sd, feats.to(dtype))
+    loss = R.caption_loss(R.decoder_forward(sd, enc, caps[:, :-1], H), caps[:, 1:])
+    loss.backward()
+    return float(loss.detach()), {k: sd[k].grad.double() for k in check}
+
+
+def _train_step_vs_oracle(model, head, feats, caps, check):
+    """One CaptionTrainer step (dropout off) at full size: loss and a sample of gradients against the oracle's
+    forward + torch autograd on the CPU.
+
+    With 5 million ReLU inputs per layer a few pre-activations lie within fp32 rounding of zero, where the ReLU
+    mask of two correct fp32 implementations differs; one flipped element (m, j) moves row j of the fc1 weight
+    gradient (and, much less, everything upstream) by dh[m,j] * x[m,:], which can exceed 1e-4 of the tensor's
+    scale.  Hence: at least 99.5 % of every tensor's entries must be within 1e-4 of the scale, and no entry may be
+    off by more than 5e-3 of it (a wrong kernel is off everywhere, by far more)."""
+    from capdec.trainer import CaptionTrainer
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    loss32, g32 = _oracle_grads(sd0, head, feats, caps, check, torch.float32)
+    model = model.cuda()
+    tr = CaptionTrainer(model, lr=1e-3)
+    got = tr.step(feats.cuda(), caps.cuda())
+    assert abs(float(got.item()) - loss32) <= 1e-4 * abs(loss32)
+    big = max(float(g32[k].abs().max()) for k in check)
+    for k in check:
+        mine = tr.grads[k].detach().cpu().double()
+        scale = float(g32[k].abs().max())
+        err = (mine - g32[k]).abs()
+        tol = REL * scale + 1e-6 * big
+        frac_bad = float((err > tol).double().mean())
+        assert frac_bad <= 5e-3 and float(err.max()) <= 5e-3 * scale + 1e-6 * big, \
+            f"{k}: {frac_bad:.2%} of entries beyond 1e-4, max err {float(err.max()):.3e}, scale {scale:.3e}"
+
+
+def test_cfg3_vit_attn_training_step_b512():
+    """BASELINE configs[2]: ViT-Attn, B=512, T=20, L=3, one memory row."""
+    from models.vitattn_model import VITAttentionModel
+    torch.manual_seed(0)
+    m = VITAttentionModel(E, V, H, 3, dropout=0.0)
+    g = torch.Generator().manual_seed(1234 + 3)
+    feats = torch.rand(512, 1000, generator=g)
+    caps = _captions(g, 512, 20, V)
+    check = ["fc2.bias", "decoder_layers.2.norm3.weight", "decoder_layers.0.self_attn.W_v.weight",
+             "decoder_layers.1.cross_attn.W_o.weight", "decoder_layers.1.feed_forward.fc1.weight",
+             "decoder_embedding.weight", "fc_vit.weight", "batchnorm.weight"]
+    _train_step_vs_oracle(m, lambda sd, f: R.head_single(sd, f, "fc_vit", training=True), feats, caps, check)
+
+
+def test_cfg4_vitcnn_attn_training_step_and_decode():
+    """BASELINE configs[3]: ViTCNN-Attn (two memory rows), B=512 training step and B=1024 greedy decode."""
+    from models.vitcnnattn_model import VITCNNAttentionModel
+    torch.manual_seed(0)
+    m = VITCNNAttentionModel(E, V, H, 2, dropout=0.0)
+    g = torch.Generator().manual_seed(1234 + 4)
+    feats = torch.rand(512, 3048, generator=g)
+    caps = _captions(g, 512, 20, V)
+    check = ["fc2.bias", "decoder_layers.1.cross_attn.W_q.weight", "decoder_layers.1.cross_attn.W_k.weight",
+             "decoder_layers.0.cross_attn.W_v.bias", "decoder_layers.0.norm2.bias", "fc_vit.weight", "fc_cnn.weight",
+             "batchnorm.bias"]
+    _train_step_vs_oracle(m, lambda sd, f: R.head_pair(sd, f, "fc_vit", 1000, training=True), feats, caps, check)
+    # decode with a fresh model (the step above moved the weights and the running statistics)
+    torch.manual_seed(1)
+    m = VITCNNAttentionModel(E, V, H, 2).eval()
+    sd = cpu_sd(m)
+    feats = torch.rand(1024, 3048, generator=g)
+    m = m.cuda()
+    got = _rows(*m.caption_ids(feats.cuda(), max_length=20))
+    rows = [0, 3, 500, 1023]
+    enc, _ = R.head_pair(sd, feats[rows], "fc_vit", 1000, training=False)
+    check_greedy([got[r] for r in rows], sd, enc, H, 20)
+    sub = _rows(*m.caption_ids(feats[128:192].cuda(), max_length=20))
+    assert sum(a != b for a, b in zip(sub, got[128:192])) <= 1
+
+
+def test_cfg5_yolocnn_attn_greedy_shard():
+    """BASELINE configs[4]: YOLOCNN-Attn greedy; one rank's shard of the 8192-row batch (1024 rows x 88484 features,
+    362 MB): the 86436-deep projection (split over workgroups) and the decode."""
+    from models.yolocnnattn_model import YOLOCNNAttentionModel
+    torch.manual_seed(0)
+    m = YOLOCNNAttentionModel(E, V, H, 2).eval()
+    with torch.no_grad():
+        m.batchnorm.running_mean.normal_(0, 0.1)
+        m.batchnorm.running_var.uniform_(0.5, 1.5)
+    sd = cpu_sd(m)
+    g = torch.Generator().manual_seed(1234 + 5)
+    feats = torch.rand(1024, 88484, generator=g)
+    m = m.cuda()
+    fd = feats.cuda()
+    rows = [0, 1, 640, 1023]
+    want_enc, _ = R.head_pair(sd, feats[rows], "fc_yolo", 86436, training=False)
+    with torch.no_grad():
+        enc = m.encode_features(fd)
+    close(enc[rows], want_enc, what="head")
+    got = _rows(*m.caption_ids(fd, max_length=20))
+    check_greedy([got[r] for r in rows], sd, want_enc, H, 20)
+    sub = _rows(*m.caption_ids(fd[512:544], max_length=20))
+    assert sum(a != b for a, b in zip(sub, got[512:544])) <= 1
