@@ -287,6 +287,88 @@ def cnnrnn_greedy_ids(sd: SD, feats: torch.Tensor, max_length: int, sos: int = S
 # --------------------------------------------------------------------------
 # loss (train.py:216,252-256)
 # --------------------------------------------------------------------------
+# --------------------------------------------------------------------------
+# beam search (transformer.py:177-244, cnnrnn_model.py:112-209): identical selection logic in both
+# --------------------------------------------------------------------------
+def beam_select(step: int, scores: torch.Tensor, done: torch.Tensor, logits: torch.Tensor, W: int):
+    """One selection step.  scores, done [B,W]; logits [B,W,V] of every live hypothesis.
+
+    Each hypothesis proposes its W most probable next tokens (log-softmax, ``topk``).  A finished hypothesis
+    keeps its score (its proposals add 0) and only its first proposal stays eligible; at the first step only
+    hypothesis 0 is eligible (all W start identical).  The best W of the W*W candidates survive, best first.
+    Returns (new scores [B,W], parent hypothesis [B,W], new token [B,W]).
+    (transformer.py:189-219 == cnnrnn_model.py:151-180)"""
+    B = scores.shape[0]
+    lp, tok = torch.log_softmax(logits, dim=-1).topk(W, dim=2)                       # [B,W,W]
+    cand = scores.unsqueeze(-1) + (1.0 - done.unsqueeze(-1).float()) * lp
+    dead = done.unsqueeze(-1).expand(-1, -1, W).clone()
+    dead[:, :, 0] = False
+    if step == 0:
+        dead[:, 1:, :] = True
+    cand = cand.masked_fill(dead, float("-inf")).reshape(B, W * W)
+    new_scores, flat = cand.topk(W, dim=-1)
+    parent = flat // W
+    new_tok = tok.reshape(B, W * W).gather(1, flat)
+    return new_scores, parent, new_tok
+
+
+def _beam_result(seqs: torch.Tensor, eos: int) -> List[List[int]]:
+    """Best hypothesis of every sample, without <SOS>, cut at its first <EOS> (transformer.py:233-241)."""
+    out = []
+    for row in seqs[:, 0].tolist():
+        out.append(row[1:row.index(eos)] if eos in row else row[1:])
+    return out
+
+
+def beam_search_ids(sd: SD, enc: torch.Tensor, H: int, W: int, max_length: int, sos: int = SOS, eos: int = EOS,
+                    return_state: bool = False):
+    """``DecoderTransformer.beam_search_inference`` up to detokenisation (transformer.py:177-244).
+    enc [B,S,E] (one memory per sample; the reference's callers repeat it W times, e.g. cnnattn_model.py:65-66).
+    Full-prefix recompute of all B*W hypotheses every step; finished hypotheses keep being extended with their
+    most probable token while their score stays frozen."""
+    B = enc.shape[0]
+    enc_w = enc.unsqueeze(1).expand(-1, W, -1, -1).reshape(B * W, enc.shape[1], enc.shape[2])
+    seqs = torch.full((B, W, 1), sos, dtype=torch.long)
+    scores = torch.zeros(B, W)
+    done = torch.zeros(B, W, dtype=torch.bool)
+    for step in range(max_length):
+        logits = decoder_forward(sd, enc_w, seqs.reshape(B * W, -1), H, take_last=True).reshape(B, W, -1)
+        scores, parent, new_tok = beam_select(step, scores, done, logits, W)
+        seqs = torch.cat([seqs.gather(1, parent.unsqueeze(-1).expand(-1, -1, seqs.shape[2])), new_tok.unsqueeze(-1)], dim=2)
+        done = done.gather(1, parent) | (new_tok == eos)
+        if bool(done.all()):
+            break
+    res = _beam_result(seqs, eos)
+    return (res, seqs, scores) if return_state else res
+
+
+def cnnrnn_beam_search_ids(sd: SD, feats: torch.Tensor, W: int, max_length: int, sos: int = SOS, eos: int = EOS,
+                           return_state: bool = False):
+    """``CNNtoRNN.caption_images_beam_search`` up to detokenisation (cnnrnn_model.py:112-209): the LSTM state of
+    every hypothesis follows its parent."""
+    B = feats.shape[0]
+    h, c, _ = rnn_image_state(sd, feats, False)
+    Hd = h.shape[1]
+    h = h.unsqueeze(1).expand(-1, W, -1).reshape(B * W, Hd)
+    c = c.unsqueeze(1).expand(-1, W, -1).reshape(B * W, Hd)
+    seqs = torch.full((B, W, 1), sos, dtype=torch.long)
+    scores = torch.zeros(B, W)
+    done = torch.zeros(B, W, dtype=torch.bool)
+    for step in range(max_length):
+        emb = sd["embed.weight"][seqs[:, :, -1].reshape(B * W)]
+        h, c = lstm_cell(emb, h, c, *_lstm_w(sd))
+        logits = linear(h, sd["fc2.weight"], sd["fc2.bias"]).reshape(B, W, -1)
+        scores, parent, new_tok = beam_select(step, scores, done, logits, W)
+        seqs = torch.cat([seqs.gather(1, parent.unsqueeze(-1).expand(-1, -1, seqs.shape[2])), new_tok.unsqueeze(-1)], dim=2)
+        idx = (torch.arange(B).unsqueeze(1) * W + parent).reshape(B * W)
+        h, c = h[idx], c[idx]
+        done = done.gather(1, parent) | (new_tok == eos)
+        if bool(done.all()):
+            break
+    res = _beam_result(seqs, eos)
+    return (res, seqs, scores) if return_state else res
+
+
 def caption_loss(logits: torch.Tensor, targets: torch.Tensor, pad: int = PAD) -> torch.Tensor:
     """``CrossEntropyLoss(ignore_index=pad)``: mean NLL over non-PAD targets."""
     V = logits.shape[-1]

@@ -181,3 +181,26 @@ def test_f7_decoder_rnn_forward_grads_step_and_greedy():
         sd2[k] = t(fx["greedy__" + k])
     got = R.cnnrnn_greedy_ids(sd2, feats, 15)
     assert got == unpad(fx["greedy_ids"])
+
+
+def test_f11_beam_search_transformer_and_rnn():
+    """Beam search restatement against the reference's beam_search_inference / caption_images_beam_search:
+    default weights (two widths), hypotheses that finish early, all finishing at once, PAD tokens inside
+    hypotheses, and the LSTM variant."""
+    fx = load_golden("f11_beam")
+    H = int(fx["H"])
+    sd = sub_sd(fx, "a__sd__")
+    for S, W, ml in ((1, 3, 12), (2, 3, 12), (2, 2, 9)):
+        got = R.beam_search_ids(sd, t(fx[f"a_enc_S{S}_W{W}"]), H, W, ml)
+        assert got == unpad(fx[f"a_ids_S{S}_W{W}"]), (S, W)
+    sdb = sub_sd(fx, "b__sd__")
+    assert R.beam_search_ids(sdb, t(fx["b_enc"]), H, 3, 20) == unpad(fx["b_ids"])
+    sdb2 = dict(sdb)
+    sdb2["fc2.bias"] = t(fx["b2__fc2.bias"])
+    assert R.beam_search_ids(sdb2, t(fx["b2_enc"]), H, 3, 20) == unpad(fx["b2_ids"])
+    assert R.beam_search_ids(sub_sd(fx, "c__sd__"), t(fx["c_enc"]), H, 3, 12) == unpad(fx["c_ids"])
+    sdr = sub_sd(fx, "r__sd__")
+    assert R.cnnrnn_beam_search_ids(sdr, t(fx["r_feats"]), 3, 15) == unpad(fx["r0_ids"])
+    sdr2 = dict(sdr)
+    sdr2["fc2.bias"] = t(fx["r__fc2.bias_biased"])
+    assert R.cnnrnn_beam_search_ids(sdr2, t(fx["r_feats"]), 3, 15) == unpad(fx["r_ids"])
