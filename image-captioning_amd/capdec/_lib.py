@@ -102,6 +102,12 @@ _SIGNATURES = {
     "capdec_tf_forward_logits": (c_int, [POINTER(TfModel), _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "capdec_rnn_decode_workspace_bytes": (c_size_t, [POINTER(RnnModel), c_int, c_int]),
     "capdec_rnn_greedy_decode": (c_int, [POINTER(RnnModel), _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
+    "capdec_tf_beam_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int, c_int]),
+    "capdec_tf_beam_search": (c_int, [POINTER(TfModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                      c_size_t, _P, _P, _P, _P, _P]),
+    "capdec_rnn_beam_workspace_bytes": (c_size_t, [POINTER(RnnModel), c_int, c_int, c_int]),
+    "capdec_rnn_beam_search": (c_int, [POINTER(RnnModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                       c_size_t, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

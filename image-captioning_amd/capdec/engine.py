@@ -199,6 +199,96 @@ def rnn_greedy_ids(rnn, x0, max_length, sos, eos):
     return out_ids.cpu(), out_len.cpu()
 
 
+def _rnn_model(rnn, E):
+    V = rnn.embed.weight.shape[0]
+    Hd = rnn.lstm.weight_hh_l0.shape[1]
+    return RnnModel(E, Hd, V, _p(rnn.embed.weight), _p(rnn.lstm.weight_ih_l0), _p(rnn.lstm.weight_hh_l0),
+                    _p(rnn.lstm.bias_ih_l0), _p(rnn.lstm.bias_hh_l0), _p(rnn.fc2.weight), _p(rnn.fc2.bias))
+
+
+BEAM_CHUNK = 8      # decode steps enqueued between two looks at the device-side "unfinished" counter
+
+
+def _beam_loop(run, B, W, max_length, dev, return_scores):
+    """Drive a beam-search entry point in chunks of steps; stop when every hypothesis is finished (the
+    reference's ``if done.all(): break``).  One 4-byte device-to-host read per chunk."""
+    out_ids = torch.empty((B, max_length), dtype=torch.int64, device=dev)
+    out_len = torch.empty((B,), dtype=torch.int32, device=dev)
+    scores = torch.empty((B, W), dtype=torch.float32, device=dev)
+    left = torch.ones(1, dtype=torch.int32, device=dev)
+    t = 0
+    while t < max_length:
+        t1 = min(max_length, t + BEAM_CHUNK)
+        run(t, t1, out_ids, out_len, scores, left)
+        t = t1
+        if t < max_length and int(left.item()) == 0:
+            break
+    if return_scores:
+        return out_ids.cpu(), out_len.cpu(), scores.cpu()
+    return out_ids.cpu(), out_len.cpu()
+
+
+def tf_beam_ids(dec, enc, beam_width, max_length, sos, eos, return_scores=False):
+    """Beam search of a DecoderTransformer (reference transformer.py:177-244).  enc [B,S,E] fp32 on the GPU, one
+    memory per sample.  Returns CPU (ids int64 [B,max_length] padded with -1, lengths int32 [B][, scores [B,W]]):
+    the best hypothesis of every sample, without <SOS>, cut at its first <EOS>."""
+    lib = _lib.load()
+    if not enc.is_cuda or enc.dtype != torch.float32:
+        raise RuntimeError("capdec: enc must be an fp32 tensor on the GPU (HIP); there is no CPU path")
+    enc = enc.contiguous()
+    B, S, _ = enc.shape
+    ref = TfModelRef(dec)
+    W = int(beam_width)
+    if not 1 <= W <= 8:
+        raise RuntimeError("capdec: beam_width must be between 1 and 8")
+    if max_length > ref.max_pos:
+        raise RuntimeError(f"capdec: max_length {max_length} exceeds the positional-encoding buffer ({ref.max_pos})")
+    if B == 0:
+        return torch.empty((0, max_length), dtype=torch.int64), torch.empty((0,), dtype=torch.int32)
+    dev = enc.device
+    with torch.cuda.device(dev):
+        nbytes = lib.capdec_tf_beam_workspace_bytes(ctypes.byref(ref.c), B, W, S, max_length)
+        if nbytes == 0:
+            raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
+        ws = _workspace(nbytes, dev)
+
+        def run(t0, t1, out_ids, out_len, scores, left):
+            _lib.check(lib.capdec_tf_beam_search(ctypes.byref(ref.c), enc.data_ptr(), B, W, S, max_length, sos, eos, t0, t1,
+                                                 ws.data_ptr(), ws.numel(), out_ids.data_ptr(), out_len.data_ptr(),
+                                                 scores.data_ptr(), left.data_ptr(), _stream()), "capdec_tf_beam_search")
+
+        return _beam_loop(run, B, W, max_length, dev, return_scores)
+
+
+def rnn_beam_ids(rnn, x0, beam_width, max_length, sos, eos, return_scores=False):
+    """Beam search of the CNN-RNN decoder (reference cnnrnn_model.py:112-209).  x0 [B,E]: BatchNorm'ed image
+    projection.  Returns as ``tf_beam_ids``."""
+    lib = _lib.load()
+    if not x0.is_cuda or x0.dtype != torch.float32:
+        raise RuntimeError("capdec: x0 must be an fp32 tensor on the GPU (HIP); there is no CPU path")
+    x0 = x0.contiguous()
+    B, E = x0.shape
+    m = _rnn_model(rnn, E)
+    W = int(beam_width)
+    if not 1 <= W <= 8:
+        raise RuntimeError("capdec: beam_width must be between 1 and 8")
+    if B == 0:
+        return torch.empty((0, max_length), dtype=torch.int64), torch.empty((0,), dtype=torch.int32)
+    dev = x0.device
+    with torch.cuda.device(dev):
+        nbytes = lib.capdec_rnn_beam_workspace_bytes(ctypes.byref(m), B, W, max_length)
+        if nbytes == 0:
+            raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
+        ws = _workspace(nbytes, dev)
+
+        def run(t0, t1, out_ids, out_len, scores, left):
+            _lib.check(lib.capdec_rnn_beam_search(ctypes.byref(m), x0.data_ptr(), B, W, max_length, sos, eos, t0, t1,
+                                                  ws.data_ptr(), ws.numel(), out_ids.data_ptr(), out_len.data_ptr(),
+                                                  scores.data_ptr(), left.data_ptr(), _stream()), "capdec_rnn_beam_search")
+
+        return _beam_loop(run, B, W, max_length, dev, return_scores)
+
+
 def ids_to_lists(ids, lengths):
     ids = ids.tolist()
     return [row[:n] for row, n in zip(ids, lengths.tolist())]

@@ -82,6 +82,143 @@ __global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __rest
     }
 }
 
+// ---- beam search bookkeeping (transformer.py:177-244, cnnrnn_model.py:112-209) --------------------------------
+constexpr int BEAM_MAX_W = 8;
+
+// One wavefront per hypothesis row: log-sum-exp of the row and its W largest logits (ties: lowest id first, as
+// torch.topk returns them on the CPU), written as log-probabilities.
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ logits, int64_t ld, int N, int V, int W,
+                                                        float* __restrict__ top_lp, int32_t* __restrict__ top_id) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* lr = logits + (int64_t)row * ld;
+    float bv[BEAM_MAX_W];
+    int bi[BEAM_MAX_W];
+#pragma unroll
+    for (int k = 0; k < BEAM_MAX_W; ++k) { bv[k] = -INFINITY; bi[k] = INT_MAX; }
+    float mx = -INFINITY, sm = 0.f;
+    for (int c = lane; c < V; c += 64) {
+        const float v = lr[c];
+        if (v > mx) { sm *= __expf(mx - v); mx = v; }
+        sm += __expf(v - mx);
+        // insert (v, c) into this lane's sorted list (ids rise with c, so a strict compare keeps the lowest id first)
+        float cv = v;
+        int ci = c;
+#pragma unroll
+        for (int k = 0; k < BEAM_MAX_W; ++k) {
+            if (k < W && cv > bv[k]) {
+                const float tv = bv[k]; const int ti = bi[k];
+                bv[k] = cv; bi[k] = ci;
+                cv = tv; ci = ti;
+            }
+        }
+    }
+    const float wm = wave_max(mx);
+    sm = wave_sum(mx > -INFINITY ? sm * __expf(mx - wm) : 0.f);
+    const float lse = wm + logf(sm);
+    for (int k = 0; k < W; ++k) {
+        float v = bv[0];
+        int i = bi[0];
+        wave_argmax(v, i);                      // best remaining head over the wave
+        if (bi[0] == i) {                       // the owning lane pops it
+#pragma unroll
+            for (int q = 0; q + 1 < BEAM_MAX_W; ++q) { bv[q] = bv[q + 1]; bi[q] = bi[q + 1]; }
+            bv[BEAM_MAX_W - 1] = -INFINITY; bi[BEAM_MAX_W - 1] = INT_MAX;
+        }
+        if (lane == 0) {
+            top_lp[(int64_t)row * W + k] = v - lse;
+            top_id[(int64_t)row * W + k] = (i >= 0 && i < V) ? i : 0;
+        }
+    }
+}
+
+struct BeamState {
+    int32_t* tok; float* score; int32_t* done;     // [N][ldtok], [N], [N]
+};
+
+__global__ void beam_init_kernel(BeamState st, int64_t ldtok, int N, int sos) {
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        st.tok[(int64_t)n * ldtok] = sos;
+        st.score[n] = 0.f;
+        st.done[n] = 0;
+    }
+}
+
+// One thread per sample: the W*W candidates of its hypotheses, best W kept (best first; ties: lowest candidate
+// index).  Writes the next state (token prefixes copied from the parents), the parent map, and counts the samples
+// that still have an unfinished hypothesis.
+__global__ void beam_select_kernel(int step, int B, int W, int eos, BeamState cur, BeamState nxt, int64_t ldtok,
+                                   const float* __restrict__ top_lp, const int32_t* __restrict__ top_id,
+                                   int32_t* __restrict__ parent, int32_t* __restrict__ n_unfinished) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float cand[BEAM_MAX_W * BEAM_MAX_W];
+    for (int w = 0; w < W; ++w) {
+        const int n = b * W + w;
+        const bool fin = cur.done[n] != 0;
+        for (int k = 0; k < W; ++k) {
+            // a finished hypothesis adds (1 - 1) * log-prob: its score stays, and only its first proposal survives
+            float v = cur.score[n] + (fin ? 0.f : 1.f) * top_lp[(int64_t)n * W + k];
+            if ((fin && k > 0) || (step == 0 && w > 0)) v = -INFINITY;
+            cand[w * W + k] = v;
+        }
+    }
+    bool every = true;
+    unsigned long long taken = 0ull;
+    for (int r = 0; r < W; ++r) {
+        int best = -1;
+        float bvv = 0.f;
+        for (int q = 0; q < W * W; ++q) {
+            if ((taken >> q) & 1ull) continue;
+            if (best < 0 || cand[q] > bvv) { bvv = cand[q]; best = q; }
+        }
+        taken |= 1ull << best;
+        const int pw = best / W, pk = best - pw * W;
+        const int src = b * W + pw, dst = b * W + r;
+        const int tokn = top_id[(int64_t)src * W + pk];
+        for (int p = 0; p <= step; ++p) nxt.tok[(int64_t)dst * ldtok + p] = cur.tok[(int64_t)src * ldtok + p];
+        nxt.tok[(int64_t)dst * ldtok + step + 1] = tokn;
+        nxt.score[dst] = bvv;
+        const int fin = (cur.done[src] != 0 || tokn == eos) ? 1 : 0;
+        nxt.done[dst] = fin;
+        parent[dst] = src;
+        every = every && fin;
+    }
+    if (!every) atomicAdd(n_unfinished, 1);
+}
+
+// dst[n,:] = src[parent[n],:]
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ parent,
+                                                          int div, int N, int D, float* __restrict__ dst) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const int from = parent ? parent[row] : row / div;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + (int64_t)from * D);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst + (int64_t)row * D);
+    for (int c = lane; c < D / 4; c += 64) d4[c] = s4[c];
+}
+
+// Best hypothesis of every sample without <SOS>, cut at its first <EOS> (transformer.py:233-241)
+__global__ void beam_result_kernel(BeamState st, int64_t ldtok, int B, int W, int steps, int max_len, int eos,
+                                   int64_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
+                                   float* __restrict__ out_scores) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int32_t* row = st.tok + (int64_t)b * W * ldtok;
+    int n = 0;
+    for (int p = 1; p <= steps; ++p) {
+        const int tk = row[p];
+        if (tk == eos) break;
+        out_ids[(int64_t)b * max_len + n++] = tk;
+    }
+    for (int p = n; p < max_len; ++p) out_ids[(int64_t)b * max_len + p] = -1;
+    out_len[b] = n;
+    if (out_scores)
+        for (int w = 0; w < W; ++w) out_scores[b * W + w] = st.score[b * W + w];
+}
+
 int check_model(const capdec_tf_model* m) {
     CAPDEC_REQUIRE(m && m->E >= 16 && m->E % 4 == 0 && m->H >= 1 && m->E % m->H == 0 && m->L >= 0 && m->V >= 1 &&
                    m->max_pos >= 1);
@@ -586,6 +723,167 @@ int capdec_rnn_greedy_decode(const capdec_rnn_model* m, const float* x0, int B, 
                            (const float*)nullptr, E, V, last ? nullptr : w.x);
         CAPDEC_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// =================================================================================================
+// Beam search (full-prefix recompute of all B*W hypotheses every step, like the reference)
+// =================================================================================================
+struct BeamBufs {
+    float *logits, *top_lp;
+    int32_t *top_id, *parent;
+    BeamState st[2];
+};
+
+static void carve_beam_bufs(Carver& c, int N, int W, int V, int max_len, BeamBufs* d) {
+    d->logits = c.take<float>((size_t)N * V);
+    d->top_lp = c.take<float>((size_t)N * W);
+    d->top_id = c.take<int32_t>((size_t)N * W);
+    d->parent = c.take<int32_t>((size_t)N);
+    for (int n = 0; n < 2; ++n) {
+        d->st[n].tok = c.take<int32_t>((size_t)N * (max_len + 1));
+        d->st[n].score = c.take<float>((size_t)N);
+        d->st[n].done = c.take<int32_t>((size_t)N);
+    }
+}
+
+static int beam_pick(const BeamBufs& d, int t, int B, int W, int V, int eos, int64_t ldtok, int32_t* n_unfinished,
+                     hipStream_t s) {
+    const int N = B * W;
+    hipLaunchKernelGGL(beam_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d.logits, (int64_t)V, N, V, W, d.top_lp,
+                       d.top_id);
+    CAPDEC_LAUNCH_CHECK();
+    if (hipMemsetAsync(n_unfinished, 0, sizeof(int32_t), s) != hipSuccess) return (int)hipGetLastError();
+    hipLaunchKernelGGL(beam_select_kernel, dim3((B + 63) / 64), dim3(64), 0, s, t, B, W, eos, d.st[t & 1],
+                       d.st[(t + 1) & 1], ldtok, d.top_lp, d.top_id, d.parent, n_unfinished);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+struct TfBeamWs {
+    FullWs f;
+    float* encx;
+    BeamBufs b;
+};
+
+static size_t carve_tf_beam(const capdec_tf_model* m, int B, int W, int S, int max_len, void* base, TfBeamWs* w) {
+    const int N = B * W;
+    TfBeamWs d;
+    const size_t head = carve_full(m, N, S, max_len, false, base, &d.f);
+    Carver c(base ? (char*)base + head : nullptr);
+    d.encx = c.take<float>((size_t)N * S * m->E);
+    carve_beam_bufs(c, N, W, m->V, max_len, &d.b);
+    if (w) *w = d;
+    return head + c.off;
+}
+
+size_t capdec_tf_beam_workspace_bytes(const capdec_tf_model* m, int B, int W, int S, int max_len) {
+    if (check_model(m) != 0 || B < 0 || W < 1 || W > BEAM_MAX_W || S < 1 || max_len < 1) return 0;
+    return carve_tf_beam(m, B, W, S, max_len, nullptr, nullptr);
+}
+
+int capdec_tf_beam_search(const capdec_tf_model* m, const float* enc, int B, int W, int S, int max_len, int sos, int eos,
+                          int t_begin, int t_end, void* workspace, size_t workspace_bytes, int64_t* out_ids,
+                          int32_t* out_len, float* out_scores, int32_t* n_unfinished, void* stream) {
+    CAPDEC_TRY(check_model(m));
+    CAPDEC_REQUIRE(enc && out_ids && out_len && n_unfinished && B >= 0 && W >= 1 && W <= BEAM_MAX_W && S >= 1 && S <= 2048);
+    CAPDEC_REQUIRE(max_len >= 1 && max_len <= m->max_pos && sos >= 0 && sos < m->V && m->V >= W);
+    CAPDEC_REQUIRE(0 <= t_begin && t_begin < t_end && t_end <= max_len);
+    if (B == 0) return 0;
+    if (!workspace || !capdec_aligned16(workspace) || !capdec_aligned16(enc)) return CAPDEC_EALIGN;
+    TfBeamWs w;
+    if (carve_tf_beam(m, B, W, S, max_len, workspace, &w) > workspace_bytes) return CAPDEC_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->E, V = m->V, N = B * W;
+    const int64_t ldtok = max_len + 1;
+    if (t_begin == 0) {
+        hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos);
+        CAPDEC_LAUNCH_CHECK();
+        // every hypothesis of a sample attends to the sample's memory rows (cnnattn_model.py:65-66)
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, enc, (const int32_t*)nullptr, W, N,
+                           S * E, w.encx);
+        CAPDEC_LAUNCH_CHECK();
+        CAPDEC_TRY(project_memory(m, w.encx, N, S, w.f.ck, w.f.cv, s));
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+        const int T = t + 1;
+        const BeamState& cur = w.b.st[t & 1];
+        CAPDEC_TRY(capdec_embed_pe(cur.tok, 1, ldtok, m->emb, m->pe, 0, N, T, E, V, w.f.f.X, stream));
+        CAPDEC_TRY(decoder_stack_full(m, w.f.f, w.f.ck, w.f.cv, N, S, T, cur.tok, ldtok, s));
+        CAPDEC_TRY(linear(w.f.f.X + (size_t)(T - 1) * E, (int64_t)T * E, N, m->fc2_w, m->fc2_b, V, E, w.b.logits, V,
+                          nullptr, 0, 0, s));
+        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, n_unfinished, s));
+    }
+    hipLaunchKernelGGL(beam_result_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.b.st[t_end & 1], ldtok, B, W, t_end,
+                       max_len, eos, out_ids, out_len, out_scores);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+struct RnnBeamWs {
+    float *x, *h[2], *c[2];
+    BeamBufs b;
+};
+
+static size_t carve_rnn_beam(const capdec_rnn_model* m, int B, int W, int max_len, void* base, RnnBeamWs* w) {
+    const int N = B * W;
+    Carver c(base);
+    RnnBeamWs d;
+    d.x = c.take<float>((size_t)N * m->E);
+    for (int n = 0; n < 2; ++n) {
+        d.h[n] = c.take<float>((size_t)N * m->Hd);
+        d.c[n] = c.take<float>((size_t)N * m->Hd);
+    }
+    carve_beam_bufs(c, N, W, m->V, max_len, &d.b);
+    if (w) *w = d;
+    return c.off;
+}
+
+size_t capdec_rnn_beam_workspace_bytes(const capdec_rnn_model* m, int B, int W, int max_len) {
+    if (check_rnn(m) != 0 || B < 0 || W < 1 || W > BEAM_MAX_W || max_len < 1) return 0;
+    return carve_rnn_beam(m, B, W, max_len, nullptr, nullptr);
+}
+
+int capdec_rnn_beam_search(const capdec_rnn_model* m, const float* x0, int B, int W, int max_len, int sos, int eos,
+                           int t_begin, int t_end, void* workspace, size_t workspace_bytes, int64_t* out_ids,
+                           int32_t* out_len, float* out_scores, int32_t* n_unfinished, void* stream) {
+    CAPDEC_TRY(check_rnn(m));
+    CAPDEC_REQUIRE(x0 && out_ids && out_len && n_unfinished && B >= 0 && W >= 1 && W <= BEAM_MAX_W && max_len >= 1);
+    CAPDEC_REQUIRE(sos >= 0 && sos < m->V && m->V >= W && 0 <= t_begin && t_begin < t_end && t_end <= max_len);
+    if (B == 0) return 0;
+    if (!workspace || !capdec_aligned16(workspace) || !capdec_aligned16(x0)) return CAPDEC_EALIGN;
+    RnnBeamWs w;
+    if (carve_rnn_beam(m, B, W, max_len, workspace, &w) > workspace_bytes) return CAPDEC_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->E, Hd = m->Hd, V = m->V, N = B * W;
+    const int64_t ldtok = max_len + 1;
+    if (t_begin == 0) {
+        hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos);
+        CAPDEC_LAUNCH_CHECK();
+        // the image is time-step 0 of the LSTM (cnnrnn_model.py:129); every hypothesis starts from that state (:133-134)
+        CAPDEC_TRY(capdec_lstm_step(x0, E, nullptr, 0, nullptr, m->w_ih, m->w_hh, m->b_ih, m->b_hh, B, E, Hd, w.h[1], Hd,
+                                    w.c[1], nullptr, stream));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w.h[1], (const int32_t*)nullptr, W, N,
+                           Hd, w.h[0]);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w.c[1], (const int32_t*)nullptr, W, N,
+                           Hd, w.c[0]);
+        CAPDEC_LAUNCH_CHECK();
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+        const BeamState& cur = w.b.st[t & 1];
+        CAPDEC_TRY(capdec_embed_pe(cur.tok + t, 1, ldtok, m->emb, nullptr, 0, N, 1, E, V, w.x, stream));
+        CAPDEC_TRY(capdec_lstm_step(w.x, E, w.h[0], Hd, w.c[0], m->w_ih, m->w_hh, m->b_ih, m->b_hh, N, E, Hd, w.h[1], Hd,
+                                    w.c[1], nullptr, stream));
+        CAPDEC_TRY(linear(w.h[1], Hd, N, m->fc2_w, m->fc2_b, V, Hd, w.b.logits, V, nullptr, 0, 0, s));
+        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, n_unfinished, s));
+        // the state of every surviving hypothesis follows its parent (cnnrnn_model.py:186-188)
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w.h[1], w.b.parent, 1, N, Hd, w.h[0]);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w.c[1], w.b.parent, 1, N, Hd, w.c[0]);
+        CAPDEC_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(beam_result_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.b.st[t_end & 1], ldtok, B, W, t_end,
+                       max_len, eos, out_ids, out_len, out_scores);
+    CAPDEC_LAUNCH_CHECK();
     return 0;
 }
 

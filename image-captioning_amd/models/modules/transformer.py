@@ -120,5 +120,23 @@ class DecoderTransformer(ABC, nn.Module):
         itos = vocabulary.itos
         return [" ".join(itos[i] for i in row) for row in engine.ids_to_lists(ids, lengths)]
 
+    # -- beam search ---------------------------------------------------------------------------
+    def beam_ids(self, enc_output, sos, eos, beam_width, max_length, return_scores=False):
+        """Best hypothesis per sample as token ids (ids int64 [B,max_length] padded with -1, lengths [B]) on the CPU.
+        enc_output [B,S,E]: one memory per sample."""
+        return engine.tf_beam_ids(self, enc_output, beam_width, max_length, sos, eos, return_scores=return_scores)
+
     def beam_search_inference(self, enc_output, batch_size, vocabulary, beam_width, max_length):
-        raise NotImplementedError("beam search is not part of the MI355X hot path yet (greedy only)")
+        """Reference transformer.py:177-244: list of ``batch_size`` space-joined captions.  ``enc_output`` is
+        [batch_size * beam_width, S, E] with every sample's memory repeated beam_width times, as the reference's
+        callers build it (cnnattn_model.py:65-66); [batch_size, S, E] is accepted too."""
+        if enc_output.shape[0] == batch_size * beam_width and beam_width > 1:
+            enc_output = enc_output[::beam_width]
+        elif enc_output.shape[0] != batch_size:
+            raise RuntimeError(f"capdec: enc_output has {enc_output.shape[0]} rows for batch_size {batch_size} x "
+                               f"beam_width {beam_width}")
+        with torch.no_grad():
+            ids, lengths = self.beam_ids(enc_output, vocabulary.stoi["<SOS>"], vocabulary.stoi["<EOS>"], beam_width,
+                                         max_length)
+        itos = vocabulary.itos
+        return [" ".join(itos[i] for i in row) for row in engine.ids_to_lists(ids, lengths)]

@@ -43,4 +43,14 @@ class VITAttentionModel(DecoderTransformer):
             return self.greedy_ids(enc_output, sos, eos, max_length)
 
     def caption_images_beam_search(self, images, vocabulary, beam_width=3, mode="precomputed", max_length=50):
-        raise NotImplementedError("beam search is not part of the MI355X hot path yet (greedy only)")
+        self.eval()
+        with torch.no_grad():
+            enc_output = self.encode_features(images, mode)
+        return self.beam_search_inference(enc_output, enc_output.shape[0], vocabulary, beam_width, max_length)
+
+    def caption_ids_beam(self, images, sos=1, eos=2, beam_width=3, mode="precomputed", max_length=50):
+        """Beam search returning token ids: (ids int64 [B,max_length] padded with -1, lengths [B])."""
+        self.eval()
+        with torch.no_grad():
+            enc_output = self.encode_features(images, mode)
+            return self.beam_ids(enc_output, sos, eos, beam_width, max_length)

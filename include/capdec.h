@@ -302,6 +302,29 @@ int capdec_rnn_greedy_decode(const capdec_rnn_model* m, const float* x0, int B, 
                              void* workspace, size_t workspace_bytes, int64_t* out_ids, int32_t* out_len,
                              void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Beam search.  Replaces DecoderTransformer.beam_search_inference (transformer.py:177-244) and the loop of
+ * CNNtoRNN.caption_images_beam_search (cnnrnn_model.py:131-197).  B samples, W hypotheses each (W <= 8); all B*W
+ * hypotheses are extended every step: per hypothesis the W most probable next tokens (log-softmax), finished
+ * hypotheses keep their score and one proposal, the first step expands hypothesis 0 only, the best W of the W*W
+ * candidates survive (best first).  The Transformer form recomputes the full prefix each step, as the reference
+ * does, so generated <PAD> tokens behave exactly as there.
+ * One call runs steps [t_begin, t_end) (t_begin == 0 initialises the state held in the workspace) and then writes
+ * the current best hypothesis of every sample (without <SOS>, cut at its first <EOS>) to out_ids [B,max_len] (padded
+ * with -1) / out_len [B], the W scores to out_scores [B,W] (nullable), and to n_unfinished[0] (device) the number of
+ * samples that still have an unfinished hypothesis: the caller may stop issuing steps once it reads 0 there (the
+ * reference's `if done.all(): break`); further steps would not change the result.
+ * ------------------------------------------------------------------------------------------ */
+size_t capdec_tf_beam_workspace_bytes(const capdec_tf_model* m, int B, int W, int S, int max_len);
+int capdec_tf_beam_search(const capdec_tf_model* m, const float* enc /*[B,S,E]*/, int B, int W, int S, int max_len,
+                          int sos, int eos, int t_begin, int t_end, void* workspace, size_t workspace_bytes,
+                          int64_t* out_ids, int32_t* out_len, float* out_scores, int32_t* n_unfinished, void* stream);
+size_t capdec_rnn_beam_workspace_bytes(const capdec_rnn_model* m, int B, int W, int max_len);
+/* x0 [B,E]: the BatchNorm'ed image projection (time-step 0 of the LSTM) */
+int capdec_rnn_beam_search(const capdec_rnn_model* m, const float* x0, int B, int W, int max_len, int sos, int eos,
+                           int t_begin, int t_end, void* workspace, size_t workspace_bytes, int64_t* out_ids,
+                           int32_t* out_len, float* out_scores, int32_t* n_unfinished, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,106 @@
+"""GPU parity of beam search (Transformer and CNN-RNN) against the golden vectors produced by the reference's
+beam_search_inference / caption_images_beam_search, and against the oracle's hypothesis scores."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Vocab, load_golden, sub_sd, unpad
+from gpu_util import close, decoder_from_sd
+from oracle import decoder_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def _rows(ids, lengths):
+    from capdec.engine import ids_to_lists
+    return ids_to_lists(ids, lengths)
+
+
+@pytest.mark.parametrize("case", ["a_S1_W3", "a_S2_W3", "a_S2_W2", "b", "b2", "c"])
+def test_f11_transformer_beam_search(case):
+    fx = load_golden("f11_beam")
+    H = int(fx["H"])
+    if case.startswith("a_"):
+        _, S, W = case.split("_")
+        W = int(W[1:])
+        sd, enc, want = sub_sd(fx, "a__sd__"), t(fx[f"a_enc_{S}_W{W}"]), unpad(fx[f"a_ids_{S}_W{W}"])
+        ml = fx[f"a_ids_{S}_W{W}"].shape[1]
+    else:
+        W = 3
+        sd = sub_sd(fx, ("b" if case == "b2" else case) + "__sd__")
+        if case == "b2":
+            sd["fc2.bias"] = t(fx["b2__fc2.bias"])
+        enc, want, ml = t(fx[case + "_enc"]), unpad(fx[case + "_ids"]), fx[case + "_ids"].shape[1]
+    dec = decoder_from_sd(sd, H)
+    ids, lengths, scores = dec.beam_ids(enc.cuda(), R.SOS, R.EOS, W, ml, return_scores=True)
+    assert _rows(ids, lengths) == want
+    # the hypothesis scores (sums of log-probabilities, frozen once finished) against the oracle's
+    _, _, want_scores = R.beam_search_ids(sd, enc, H, W, ml, return_state=True)
+    close(scores, want_scores, rtol=1e-4, atol=1e-5, what="scores")
+
+
+def test_f11_beam_api_strings_and_repeated_memory():
+    """beam_search_inference takes the memory repeated per hypothesis, as the reference's callers pass it."""
+    fx = load_golden("f11_beam")
+    H = int(fx["H"])
+    sd = sub_sd(fx, "a__sd__")
+    dec = decoder_from_sd(sd, H)
+    enc = t(fx["a_enc_S2_W3"]).cuda()
+    B = enc.shape[0]
+    rep = enc.unsqueeze(1).expand(-1, 3, -1, -1).reshape(B * 3, 2, -1)
+    vocab = Vocab(50)
+    text = dec.beam_search_inference(rep, B, vocab, 3, 12)
+    want = [" ".join(vocab.itos[i] for i in row) for row in unpad(fx["a_ids_S2_W3"])]
+    assert text == want
+    assert dec.beam_search_inference(enc, B, vocab, 3, 12) == want
+    with pytest.raises(RuntimeError):
+        dec.beam_ids(enc, R.SOS, R.EOS, 9, 12)
+    with pytest.raises(RuntimeError):
+        dec.beam_ids(enc, R.SOS, R.EOS, 3, 51)
+
+
+def test_beam_width_one_is_greedy():
+    fx = load_golden("f11_beam")
+    H = int(fx["H"])
+    sd = sub_sd(fx, "c__sd__")
+    dec = decoder_from_sd(sd, H)
+    enc = t(fx["c_enc"])
+    got = _rows(*dec.beam_ids(enc.cuda(), R.SOS, R.EOS, 1, 12))
+    assert got == R.greedy_inference_ids(sd, enc, H, 12)
+
+
+@pytest.mark.parametrize("case", ["r0", "r"])
+def test_f11_cnn_rnn_beam_search(case):
+    from models.cnnrnn_model import CNNtoRNN
+    fx = load_golden("f11_beam")
+    sd = sub_sd(fx, "r__sd__")
+    if case == "r":
+        sd["fc2.bias"] = t(fx["r__fc2.bias_biased"])
+    E, Hd, V = sd["fc1.weight"].shape[0], sd["lstm.weight_hh_l0"].shape[1], sd["embed.weight"].shape[0]
+    m = CNNtoRNN(E, Hd, V)
+    m.decoderRNN.load_state_dict(sd)
+    m = m.cuda().eval()
+    feats = t(fx["r_feats"])
+    got = _rows(*m.caption_ids_beam(feats.cuda(), beam_width=3, max_length=15))
+    assert got == unpad(fx[case + "_ids"])
+    vocab = Vocab(V)
+    text = m.caption_images_beam_search(feats.cuda(), vocab, beam_width=3, max_length=15)
+    assert text == [" ".join(vocab.itos[i] for i in row) for row in got]
+
+
+def test_beam_medium_size_against_oracle():
+    """E=512, V=10000, L=2, B=6, W=3, 10 steps: best hypotheses and scores against the oracle."""
+    from gpu_util import cpu_sd, plain_decoder
+    torch.manual_seed(0)
+    dec = plain_decoder(512, 10000, 4, 2).cuda().eval()
+    sd = cpu_sd(dec)
+    g = torch.Generator().manual_seed(77)
+    enc = torch.randn(6, 2, 512, generator=g)
+    ids, lengths, scores = dec.beam_ids(enc.cuda(), R.SOS, R.EOS, 3, 10, return_scores=True)
+    want, _, want_scores = R.beam_search_ids(sd, enc, 4, 3, 10, return_state=True)
+    close(scores, want_scores, rtol=1e-4, atol=1e-4, what="scores")
+    assert _rows(ids, lengths) == want
