@@ -158,5 +158,12 @@ class CaptionTrainer:
             w.wait()
         return loss
 
+    def scheduler_step(self, epoch, step_size=5, gamma=0.8):
+        """``StepLR(step_size=5, gamma=0.8)`` stepped once per epoch (reference train.py:218,366): call after epoch
+        number ``epoch`` (0-based) has finished; returns the learning rate of the next epoch."""
+        if (epoch + 1) % step_size == 0:
+            self.lr *= gamma
+        return self.lr
+
     def grad_bytes(self):
         return self.flat_g.numel() * 4

@@ -316,3 +316,47 @@ def test_attention_backward_one_pass_matches_two_pass(B, H, Tq, Tk, dk, causal):
         lib.capdec_attention_bwd_force_two_pass(0)
     for a, b, name in zip(one, two, ("dq", "dk", "dv")):
         close(a, b.cpu().numpy(), rtol=1e-5, what=name)
+
+
+def test_checkpoint_roundtrip_resumes_training_exactly(tmp_path):
+    """Save after two steps in the reference's checkpoint schema, load into a fresh model + trainer, take one more
+    step on both: weights, Adam moments and step counter must carry over (dropout off, so steps are deterministic
+    up to the float atomics in the weight gradients)."""
+    from capdec.checkpoint import load_reference_checkpoint, save_reference_checkpoint
+    from capdec.trainer import CaptionTrainer
+    from models.vitattn_model import VITAttentionModel
+    torch.manual_seed(11)
+    g = torch.Generator().manual_seed(12)
+    feats = torch.rand(16, 1000, generator=g).cuda()
+    caps = torch.randint(4, 90, (16, 9), generator=g)
+    caps[:, 0] = 1
+    caps[:, -1] = 2
+    caps = caps.cuda()
+    a = VITAttentionModel(64, 90, 4, 2, dropout=0.0).cuda()
+    ta = CaptionTrainer(a, lr=2e-3)
+    for _ in range(2):
+        ta.step(feats, caps)
+    path = str(tmp_path / "ck.pth.tar")
+    save_reference_checkpoint(path, a, ta, step=2)
+    b = VITAttentionModel(64, 90, 4, 2, dropout=0.0).cuda()
+    tb = CaptionTrainer(b, lr=1e-3)
+    assert load_reference_checkpoint(path, b, tb) == 2
+    assert tb.t == 2 and abs(tb.lr - 2e-3) < 1e-12
+    la, lb = ta.step(feats, caps), tb.step(feats, caps)
+    close(lb, la.detach().cpu().numpy(), rtol=1e-5, what="loss after resume")
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        if va.is_floating_point():
+            assert float((va - vb).abs().max()) <= 2.2 * 2e-3 * 1e-2 + 1e-6, k      # same step up to atomics' rounding
+
+
+def test_feature_store_batches_on_gpu(tmp_path):
+    from capdec.feature_store import FeatureStore
+    g = torch.Generator().manual_seed(5)
+    feats = torch.rand(1000, 128, generator=g)
+    st = FeatureStore.from_arrays(str(tmp_path / "fs"), list(range(1000)), feats.numpy())
+    order = torch.randperm(1000, generator=g).numpy()
+    n = 0
+    for r, x in st.batches(192, "cuda", order=order):
+        assert x.is_cuda and torch.equal(x.cpu(), feats[torch.from_numpy(r)])
+        n += len(r)
+    assert n == 1000

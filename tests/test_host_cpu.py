@@ -127,3 +127,60 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text, f"{f} mentions the oracle"
+
+
+def test_feature_store_roundtrip_and_batches(tmp_path):
+    from capdec.feature_store import FeatureStore, import_pickle_dir
+    g = torch.Generator().manual_seed(3)
+    feats = torch.rand(37, 24, generator=g)
+    ids = [f"img_{i:03d}" for i in range(37)]
+    FeatureStore.from_arrays(str(tmp_path / "s"), ids, feats.numpy())
+    st = FeatureStore(str(tmp_path / "s"))
+    assert len(st) == 37 and st.dim == 24
+    rows = st.rows(["img_005", "img_000", "img_036"])
+    assert torch.equal(st.gather(rows), feats[[5, 0, 36]])
+    order = torch.randperm(37, generator=g).numpy()
+    seen = []
+    for r, x in st.batches(8, "cpu", order=order):
+        assert torch.equal(x, feats[torch.from_numpy(r)])
+        seen.extend(r.tolist())
+    assert seen == order.tolist()
+    assert sum(len(r) for r, _ in st.batches(8, "cpu", drop_last=True)) == 32
+    # the reference's per-image pickles (pickle.dump of a tensor) convert without executing anything else
+    import pickle
+    src = tmp_path / "pk"
+    src.mkdir()
+    for i in range(5):
+        with open(src / f"{ids[i]}.pkl", "wb") as fh:
+            pickle.dump(feats[i].clone(), fh)
+    st2 = import_pickle_dir(str(src), str(tmp_path / "s2"))
+    assert torch.equal(torch.from_numpy(np.asarray(st2.data)), feats[:5])
+    with open(src / "evil.pkl", "wb") as fh:
+        pickle.dump(os.system, fh)
+    with pytest.raises(Exception):
+        import_pickle_dir(str(src), str(tmp_path / "s3"))
+
+
+def test_reference_checkpoint_load_filters_backbone(tmp_path):
+    """A reference checkpoint holds the full model (backbone first); loading keeps the keys this package owns."""
+    from capdec.checkpoint import load_reference_checkpoint, save_reference_checkpoint
+    from models.cnnattn_model import CNNAttentionModel
+    torch.manual_seed(1)
+    src = CNNAttentionModel(64, 50, 4, 1)
+    sd = {"encoderCNN.inception.Conv2d_1a_3x3.conv.weight": torch.randn(4, 3, 3, 3),
+          "encoderCNN.inception.Conv2d_1a_3x3.bn.running_mean": torch.zeros(4)}
+    sd.update(src.state_dict())
+    path = str(tmp_path / "ref.pth.tar")
+    torch.save({"state_dict": sd, "optimizer": {"state": {}, "param_groups": [{"lr": 3e-4}]}, "step": 1234}, path)
+    dst = CNNAttentionModel(64, 50, 4, 1)
+    assert load_reference_checkpoint(path, dst) == 1234
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    out = save_reference_checkpoint(str(tmp_path / "out.pth.tar"), dst, step=7,
+                                    backbone_state={k: v for k, v in sd.items() if k.startswith("encoderCNN.")})
+    assert list(out["state_dict"])[:2] == list(sd)[:2] and out["step"] == 7
+    again = torch.load(str(tmp_path / "out.pth.tar"), weights_only=True)
+    assert set(again["state_dict"]) == set(sd)
+    del sd["fc1.weight"]
+    with pytest.raises(RuntimeError, match="lacks"):
+        load_reference_checkpoint({"state_dict": sd, "step": 0}, dst)
