@@ -122,6 +122,9 @@ def load():
         raise RuntimeError(
             f"libcapdec.so not found at {LIB_PATH}: the HIP kernels are the only implementation of this package "
             "(no CPU fallback). Build them with `python image-captioning_amd/capdec/_build.py` (needs hipcc).")
+    # PyTorch ships its own HIP runtime; it must be the one already mapped when libcapdec.so resolves its HIP symbols,
+    # or the process ends up with two runtimes and this library's copy finds no device.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         try:
