@@ -588,7 +588,8 @@ int launch_gemm_layout(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, 
     return launch_gemm_cfg<2, 1, 1, 32, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
 }
 
-constexpr int VOCAB_BI = 128;   // vocabulary ids per tile of the fused projections
+constexpr int VOCAB_WI = 1;                 // 32-row accumulator blocks per wavefront along the vocabulary axis
+constexpr int VOCAB_BI = 64 * VOCAB_WI;     // vocabulary ids per tile of the fused projections
 
 }  // namespace
 
@@ -657,14 +658,14 @@ static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const floa
     const bool vec = (K % 4 == 0) && (ldx % 4 == 0) && capdec_aligned16(x) && capdec_aligned16(W);
     // samples sit on the j (lane) axis: 128-wide tiles when there are enough rows to fill the chip
     const bool wide = ((long)nt * ((M + 127) / 128) >= 192);
-    constexpr int VBK = 16;   // 128x128 tile at BK 16: 40 KiB of LDS, three workgroups per CU
-    constexpr size_t smem_w = lds_floats<2, 2, 2, VBK, false, false, 1>() * sizeof(float);
-    constexpr size_t smem_n = lds_floats<2, 2, 1, VBK, false, false, 1>() * sizeof(float);
+    constexpr int VBK = 16;   // 64x128 tile at BK 16: 30 KiB of LDS, five workgroups per CU (1256 tiles at V=10000, M=1024: 4.9 per CU)
+    constexpr size_t smem_w = lds_floats<2, VOCAB_WI, 2, VBK, false, false, 1>() * sizeof(float);
+    constexpr size_t smem_n = lds_floats<2, VOCAB_WI, 1, VBK, false, false, 1>() * sizeof(float);
     const size_t smem = wide ? smem_w : smem_n;
     TileMap map;
     dim3 grid(make_tile_map(map, nt, wide ? (M + 127) / 128 : (M + 63) / 64, 1, false), 1, 1);
 #define CAPDEC_VR(WJ_, VEC_, MODE_)                                                                                    \
-    hipLaunchKernelGGL((vocab_reduce_kernel<2, WJ_, VBK, VEC_, MODE_>), grid, dim3(256), smem, s, W, x, ldx, bias, V, \
+    hipLaunchKernelGGL((vocab_reduce_kernel<VOCAB_WI, WJ_, VBK, VEC_, MODE_>), grid, dim3(256), smem, s, W, x, ldx, bias, V, \
                        M, K, out_a, out_b, nt, map)
     if (mode == 0) {
         if (wide) { if (vec) CAPDEC_VR(2, true, 0); else CAPDEC_VR(2, false, 0); }

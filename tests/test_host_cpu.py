@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(declared) == _lib.exported_symbols()
     assert lib.capdec_abi_version() == _lib.ABI_VERSION
     assert lib.capdec_strerror(-22).decode().startswith("capdec")
-    assert lib.capdec_vocab_tiles(10000) == 79
+    assert lib.capdec_vocab_tiles(10000) == 157
 
 
 def test_argument_validation_without_gpu():
