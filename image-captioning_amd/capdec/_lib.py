@@ -81,7 +81,7 @@ _SIGNATURES = {
     "capdec_embed_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "capdec_bn_train_backward": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "capdec_attention_bwd_force_two_pass": (c_int, [c_int]),
-    "capdec_attention_bwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, _P,
+    "capdec_attention_bwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P,
                                      _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
     "capdec_loss_finish": (c_int, [_P, _P, _P, _P]),

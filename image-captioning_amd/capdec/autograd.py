@@ -129,7 +129,7 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
                 _new(grads, pre + "cross_attn." + n, prm)                              # exactly zero
         else:
             d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2)
-            dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S)
+            dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S, out=c.ao2)
             _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1)
             _lin_bwd(grads, pre + "cross_attn.W_k", ca.W_k, dk2, t.enc, need_dx=need_denc, accum=denc)
             _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, dv2, t.enc, need_dx=need_denc, accum=denc)

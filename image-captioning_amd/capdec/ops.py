@@ -377,8 +377,9 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta):
     return d_add, (d_x if p > 0 else d_add)
 
 
-def attention_bwd(q, k, v, dout, lse, B, H, Tq, Tk, causal=False, ids32=None, dq=None, dk=None, dv=None):
-    """Backward of ``attention``; q/dout [B*Tq,E], k/v [B*Tk,E] 2-D views.  Returns (dq, dk, dv)."""
+def attention_bwd(q, k, v, dout, lse, B, H, Tq, Tk, causal=False, ids32=None, dq=None, dk=None, dv=None, out=None):
+    """Backward of ``attention``; q/dout [B*Tq,E], k/v [B*Tk,E] 2-D views.  Returns (dq, dk, dv).
+    ``out`` (the forward output, optional) enables the one-pass kernel for long unmasked memories."""
     lib = _lib.load()
     E = q.shape[1]
     dkh = E // H
@@ -396,7 +397,8 @@ def attention_bwd(q, k, v, dout, lse, B, H, Tq, Tk, causal=False, ids32=None, dq
     ldk, ldv, lddk, lddv = (_row_stride(t, "kv") for t in (k, v, dk, dv))
     _lib.check(lib.capdec_attention_bwd(_chk(q).data_ptr(), _row_stride(q, "q"), _chk(k).data_ptr(), ldk, ldk * Tk,
                                         _chk(v).data_ptr(), ldv, ldv * Tk, _chk(dout).data_ptr(),
-                                        _row_stride(dout, "dout"), _chk(lse).data_ptr(), dsum.data_ptr(),
+                                        _row_stride(dout, "dout"), _ptr(out), 0 if out is None else _row_stride(out, "out"),
+                                        _chk(lse).data_ptr(), dsum.data_ptr(),
                                         dq.data_ptr(), _row_stride(dq, "dq"), dk.data_ptr(), lddk, lddk * Tk,
                                         dv.data_ptr(), lddv, lddv * Tk, B, H, Tq, Tk, dkh, 1 if causal else 0, 0,
                                         _ptr(ids32), ldid, _stream()), "capdec_attention_bwd")

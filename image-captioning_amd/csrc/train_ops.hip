@@ -367,6 +367,7 @@ struct AttnBwdArgs {
     const float* k; int64_t ldk, sk;
     const float* v; int64_t ldv, sv;
     const float* dout; int64_t ldo;
+    const float* out; int64_t ldout;   // forward output (nullable): D_i = dO_i . O_i without a sweep over the keys
     const float* lse;            // [B,H,Tq]
     float* dsum;                 // [B,H,Tq]  D_i = sum_j p_ij dp_ij (written by the query pass)
     float* dq; int64_t lddq;
@@ -642,6 +643,117 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
     }
 }
 
+// Long memory, short query block (cross-attention over a token or grid memory: Tq <= 64, any Tk, no mask): one
+// workgroup per (b,h) keeps Q, dO and a dQ accumulator in LDS and streams the keys through LDS in chunks of AB_KC.
+// D_i = sum_j P_ij dP_ij equals dO_i . O_i, so with the forward output at hand every chunk is independent: its P and
+// dS give the chunk's dK, dV rows at once (each key row is stored exactly once) and add into dQ.
+constexpr int AB_KC = 32;
+
+template <int NM>
+__global__ __launch_bounds__(256) void attn_bwd_chunked_kernel(AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dk = a.dk_, LD = dk + 16, Tq = a.Tq, Tk = a.Tk;
+    float* Qs = lds;                       // [Tq][LD]
+    float* Os = Qs + Tq * LD;              // dO [Tq][LD]
+    float* dQs = Os + Tq * LD;             // [Tq][LD]
+    float* Ks = dQs + Tq * LD;             // [AB_KC][LD]
+    float* Vs = Ks + AB_KC * LD;           // [AB_KC][LD]
+    float* Ps = Vs + AB_KC * LD;           // [Tq][AB_KC]
+    float* Ds = Ps + Tq * AB_KC;           // [Tq][AB_KC]
+    float* Dsum = Ds + Tq * AB_KC;         // [Tq]
+    float* Lse = Dsum + Tq;                // [Tq]
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int nv = dk / 4;
+    for (int idx = threadIdx.x; idx < Tq * nv; idx += 256) {
+        const int r = idx / nv, c = idx - r * nv;
+        const int64_t row = (int64_t)b * Tq + r;
+        *reinterpret_cast<f32x4*>(&Qs[r * LD + 4 * c]) =
+            *reinterpret_cast<const f32x4*>(a.q + row * a.ldq + (int64_t)h * dk + 4 * c);
+        *reinterpret_cast<f32x4*>(&Os[r * LD + 4 * c]) =
+            *reinterpret_cast<const f32x4*>(a.dout + row * a.ldo + (int64_t)h * dk + 4 * c);
+        *reinterpret_cast<f32x4*>(&dQs[r * LD + 4 * c]) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // D_i = dO_i . O_i, one wavefront per row
+    for (int i = wave; i < Tq; i += 4) {
+        const int64_t row = (int64_t)b * Tq + i;
+        float d = 0.f;
+        for (int c = lane; c < dk; c += 64)
+            d += a.dout[row * a.ldo + (int64_t)h * dk + c] * a.out[row * a.ldout + (int64_t)h * dk + c];
+        d = wave_sum(d);
+        if (lane == 0) {
+            Dsum[i] = d;
+            Lse[i] = a.lse[((int64_t)b * a.H + h) * Tq + i];
+        }
+    }
+    const float scale = sqrtf((float)dk);
+    const int part = lane & 3, kl = lane >> 2;
+    const int lpv = dk / 4, grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
+    for (int c0 = 0; c0 < Tk; c0 += AB_KC) {
+        const int nk = min(AB_KC, Tk - c0);
+        __syncthreads();                                   // previous chunk fully consumed (and the prologue done)
+        for (int idx = threadIdx.x; idx < nk * nv; idx += 256) {
+            const int r = idx / nv, c = idx - r * nv;
+            *reinterpret_cast<f32x4*>(&Ks[r * LD + 4 * c]) = *reinterpret_cast<const f32x4*>(
+                a.k + (int64_t)b * a.sk + (int64_t)(c0 + r) * a.ldk + (int64_t)h * dk + 4 * c);
+            *reinterpret_cast<f32x4*>(&Vs[r * LD + 4 * c]) = *reinterpret_cast<const f32x4*>(
+                a.v + (int64_t)b * a.sv + (int64_t)(c0 + r) * a.ldv + (int64_t)h * dk + 4 * c);
+        }
+        __syncthreads();
+        // query rows: P and dS of this chunk, dQ += dS K / sqrt(dk)
+        for (int i = wave; i < Tq; i += 4) {
+            f32x4 qreg[NM], oreg[NM];
+            load_parts(qreg, Qs + i * LD + 4 * part);
+            load_parts(oreg, Os + i * LD + 4 * part);
+            const float l = Lse[i], D = Dsum[i];
+            for (int j0 = 0; j0 < nk; j0 += 16) {
+                const int j = j0 + kl;
+                float sc = 0.f, dp = 0.f;
+                if (j < nk) {
+                    sc = dot_parts(qreg, Ks + j * LD + 4 * part);
+                    dp = dot_parts(oreg, Vs + j * LD + 4 * part);
+                }
+                sc = quad_sum(sc);
+                dp = quad_sum(dp);
+                if (j < nk && part == 0) {
+                    const float pr = expf(sc / scale - l);
+                    Ps[i * AB_KC + j] = pr;
+                    Ds[i * AB_KC + j] = pr * (dp - D);
+                }
+            }
+            // LDS serves one wavefront's accesses in order: the dS values above are visible to its other lanes
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int j = grp; j < nk; j += ngrp)
+                acc += *reinterpret_cast<const f32x4*>(Ks + j * LD + 4 * dl) * (Ds[i * AB_KC + j] / scale);
+            group_reduce(acc, lpv);
+            if (grp == 0) *reinterpret_cast<f32x4*>(dQs + i * LD + 4 * dl) += acc;     // row i belongs to this wave
+        }
+        __syncthreads();
+        // keys of the chunk: dK_j = sum_i dS_ij Q_i / sqrt(dk), dV_j = sum_i P_ij dO_i
+        for (int j = wave; j < nk; j += 4) {
+            f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+            for (int i = grp; i < Tq; i += ngrp) {
+                const float pr = Ps[i * AB_KC + j], d = Ds[i * AB_KC + j];
+                av += *reinterpret_cast<const f32x4*>(Os + i * LD + 4 * dl) * pr;
+                ak += *reinterpret_cast<const f32x4*>(Qs + i * LD + 4 * dl) * (d / scale);
+            }
+            group_reduce(ak, lpv);
+            group_reduce(av, lpv);
+            if (grp == 0) {
+                const int64_t kr = (int64_t)(c0 + j);
+                *reinterpret_cast<f32x4*>(a.dk + (int64_t)b * a.sdk + kr * a.lddk + (int64_t)h * dk + 4 * dl) = ak;
+                *reinterpret_cast<f32x4*>(a.dv + (int64_t)b * a.sdv + kr * a.lddv + (int64_t)h * dk + 4 * dl) = av;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < Tq * nv; idx += 256) {
+        const int r = idx / nv, c = idx - r * nv;
+        *reinterpret_cast<f32x4*>(a.dq + ((int64_t)b * Tq + r) * a.lddq + (int64_t)h * dk + 4 * c) =
+            *reinterpret_cast<const f32x4*>(&dQs[r * LD + 4 * c]);
+    }
+}
+
 // ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) over one flat buffer -----------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
@@ -858,7 +970,8 @@ int capdec_attention_bwd_force_two_pass(int on) {
 }
 
 int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
-                         int64_t ldv, int64_t sv, const float* dout, int64_t ldo, const float* lse, float* dsum,
+                         int64_t ldv, int64_t sv, const float* dout, int64_t ldo, const float* out, int64_t ldout,
+                         const float* lse, float* dsum,
                          float* dq, int64_t lddq, float* dk, int64_t lddk, int64_t sdk, float* dv, int64_t lddv,
                          int64_t sdv, int B, int H, int Tq, int Tk, int dkh, int causal, int causal_off,
                          const int32_t* ids, int64_t ldid, void* stream) {
@@ -871,7 +984,8 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
         ldv % 4 || sv % 4 || ldo % 4 || lddq % 4 || lddk % 4 || sdk % 4 || lddv % 4 || sdv % 4)
         return CAPDEC_EALIGN;
     if (B == 0) return 0;
-    AttnBwdArgs a{q, ldq, k, ldk, sk, v, ldv, sv, dout, ldo, lse, dsum, dq, lddq, dk, lddk, sdk, dv, lddv, sdv,
+    if (out && (!capdec_aligned16(out) || ldout % 4)) return CAPDEC_EALIGN;
+    AttnBwdArgs a{q, ldq, k, ldk, sk, v, ldv, sv, dout, ldo, out, ldout, lse, dsum, dq, lddq, dk, lddk, sdk, dv, lddv, sdv,
                   B, H, Tq, Tk, dkh, causal, causal_off, ids, ldid};
     hipStream_t s = (hipStream_t)stream;
     // short sequences: everything of one (b,h) fits in LDS
@@ -889,6 +1003,26 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
         if (!ready) return CAPDEC_EINVAL;
 #define CAPDEC_CALL(NM_) \
     hipLaunchKernelGGL(attn_bwd_fused_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), fused_lds, s, a)
+        CAPDEC_DK_DISPATCH(dkh, CAPDEC_CALL);
+#undef CAPDEC_CALL
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
+    // long unmasked memory with the forward output at hand: keys streamed through LDS in chunks
+    const size_t chunk_lds = ((size_t)(3 * Tq + 2 * AB_KC) * (dkh + 16) + (size_t)2 * Tq * AB_KC + 2 * Tq) * sizeof(float);
+    if (out && !causal && !ids && Tq <= 64 && chunk_lds <= 144 * 1024 && !g_attn_bwd_two_pass) {
+        static const bool ready = [] {
+            bool ok = true;
+#define CAPDEC_CALL(NM_)                                                                                    \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_chunked_kernel<NM_>),             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess
+            CAPDEC_CALL(1); CAPDEC_CALL(2); CAPDEC_CALL(4); CAPDEC_CALL(8); CAPDEC_CALL(16);
+#undef CAPDEC_CALL
+            return ok;
+        }();
+        if (!ready) return CAPDEC_EINVAL;
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attn_bwd_chunked_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), chunk_lds, s, a)
         CAPDEC_DK_DISPATCH(dkh, CAPDEC_CALL);
 #undef CAPDEC_CALL
         CAPDEC_LAUNCH_CHECK();

@@ -178,9 +178,11 @@ int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma
                              void* stream);
 /* Backward of capdec_attention (same layout and mask arguments): lse from the forward; dsum is scratch
  * [B,H,Tq]; dq/dk/dv are written (not accumulated).  A PAD query row has a constant uniform softmax: it
- * contributes to dv only. */
+ * contributes to dv only.  out (nullable, row stride ldout) is the forward output: with it an unmasked
+ * attention over a long memory (Tq <= 64) runs as one pass that streams the keys through LDS. */
 int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
-                         int64_t ldv, int64_t sv, const float* dout, int64_t ldo, const float* lse, float* dsum,
+                         int64_t ldv, int64_t sv, const float* dout, int64_t ldo, const float* out, int64_t ldout,
+                         const float* lse, float* dsum,
                          float* dq, int64_t lddq, float* dk, int64_t lddk, int64_t sdk, float* dv, int64_t lddv,
                          int64_t sdv, int B, int H, int Tq, int Tk, int dkh, int causal, int causal_off,
                          const int32_t* ids, int64_t ldid, void* stream);

@@ -291,7 +291,7 @@ def test_cnn_rnn_trainer_matches_oracle_training_loop():
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,dk,causal", [(5, 4, 20, 20, 128, True), (3, 2, 7, 5, 16, False), (2, 4, 50, 50, 128, True),
-                                                (4, 4, 20, 2, 64, False)])
+                                                (4, 4, 20, 2, 64, False), (3, 4, 20, 197, 128, False), (2, 2, 9, 70, 32, False)])
 def test_attention_backward_one_pass_matches_two_pass(B, H, Tq, Tk, dk, causal):
     """The LDS-resident backward for short sequences against the general two-pass kernels (both are also pinned by
     the golden gradients through the decoder tests, which use short sequences)."""
@@ -306,9 +306,9 @@ def test_attention_backward_one_pass_matches_two_pass(B, H, Tq, Tk, dk, causal):
         ids[0, Tq // 2] = 0
         ids[-1, -1] = 0
         ids32 = ids.to(torch.int32).cuda()
-    _, lse = ops.attention(q, k, v, B, H, Tq, Tk, causal=causal, ids32=ids32, want_lse=True)
+    o, lse = ops.attention(q, k, v, B, H, Tq, Tk, causal=causal, ids32=ids32, want_lse=True)
     lib = _lib.load()
-    one = ops.attention_bwd(q, k, v, do, lse, B, H, Tq, Tk, causal=causal, ids32=ids32)
+    one = ops.attention_bwd(q, k, v, do, lse, B, H, Tq, Tk, causal=causal, ids32=ids32, out=o)
     lib.capdec_attention_bwd_force_two_pass(1)
     try:
         two = ops.attention_bwd(q, k, v, do, lse, B, H, Tq, Tk, causal=causal, ids32=ids32)
