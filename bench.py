@@ -111,6 +111,86 @@ def train_bench(device, rank, world, steps, warmup, fence, note=lambda m: None):
             "loss_first": first, "loss_last": float(loss.item())}
 
 
+def variants_bench(device, steps=6, warmup=2):
+    """The shapes as BASELINE.json words them (secondary reading; the decoder is the same parity-pinned code, the
+    per-cell / per-token projections in front of it have no counterpart in the reference's classes):
+      decode over a 64-cell feature grid (S=64), and training over 197 ViT tokens of width 768 (S=197)."""
+    from capdec import autograd as AG
+    from capdec import engine, ops
+    from capdec.trainer import CaptionTrainer
+    from models.vitattn_model import VITAttentionModel
+    out = {}
+    # ---- decode, S=64 grid: per-cell Linear(2048,E) (+ folded BatchNorm) then the cached greedy decoder ----
+    model = build_model(device)
+    S = 64
+    g = torch.Generator().manual_seed(1234 + 2)
+    feats = torch.rand(B * S, D, generator=g).to(device)
+
+    def dstep():
+        with torch.no_grad():
+            enc = model.encode_features(feats).view(B, S, E)
+            return engine.tf_greedy_ids(model, enc, LEN, 1, 2, to_cpu=True)
+
+    for _ in range(warmup):
+        dstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out["decode_grid64"] = {"workload": f"CNN-Attn greedy decode over a 64x2048 feature grid (S=64), B={B}, len {LEN}",
+                            "value": B / dt, "unit": "captions/s", "ms_per_step": dt * 1e3}
+    del model, feats
+    # ---- training, S=197 tokens of width 768: Linear(768,E) per token, 3-layer decoder, loss, backward, Adam ----
+    Bt, T, Lt, St, Dt = 512, 20, 3, 197, 768
+    torch.manual_seed(0)
+    m = VITAttentionModel(E, V, H, Lt).to(device).train()
+    tr = CaptionTrainer(m, lr=1e-3)
+    w_tok = (torch.randn(E, Dt, generator=g) * Dt ** -0.5).to(device)
+    b_tok = torch.zeros(E, device=device)
+    gw, gb = torch.zeros_like(w_tok), torch.zeros_like(b_tok)
+    mw, vw = torch.zeros(E * Dt + E, device=device), torch.zeros(E * Dt + E, device=device)
+    tokens = torch.randn(Bt * St, Dt, generator=g).to(device)
+    caps = torch.randint(4, V, (Bt, T + 1), generator=g)
+    caps[:, 0] = 1
+    caps = caps.to(device)
+    ids, tgt = caps[:, :-1].contiguous(), caps[:, 1:].contiguous()
+    k = [0]
+
+    def tstep():
+        k[0] += 1
+        tr.flat_g.zero_()
+        gw.zero_()
+        gb.zero_()
+        enc = ops.linear(tokens, w_tok, b_tok)
+        x, tape = AG.tf_forward(m, enc.view(Bt, St, E), ids, m.dropout.p, AG.draw_seed())
+        loss, saved = AG.vocab_loss(m, x, tgt)
+        dx = AG.vocab_loss_bwd(m, x, saved, tr.grads)
+        denc = AG.tf_backward(m, tape, dx, tr.grads, need_denc=True)
+        ops.linear_wgrad(denc.view(Bt * St, E), tokens, out=gw)
+        ops.colsum(denc.view(Bt * St, E), gb)
+        ops.adam_step(tr.flat_p, tr.flat_g, tr.m, tr.v, 1e-3, k[0])
+        ops.adam_step(w_tok.view(-1), gw.view(-1), mw[:E * Dt], vw[:E * Dt], 1e-3, k[0])
+        ops.adam_step(b_tok, gb, mw[E * Dt:], vw[E * Dt:], 1e-3, k[0])
+        return loss
+
+    for _ in range(warmup):
+        tstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    f_fwd = Lt * (16 * T * E * E + 4 * St * E * E + 4 * T * T * E + 4 * T * St * E) + 2 * T * E * V + 2 * St * Dt * E
+    tf = 3.0 * f_fwd * Bt / dt / 1e12
+    out["train_tokens197"] = {"workload": f"ViT-Attn training over 197x768 tokens (S=197), B={Bt}, T={T}, L={Lt}, dropout 0.1, Adam",
+                              "value": Bt / dt, "unit": "samples/s", "ms_per_step": dt * 1e3,
+                              "algorithmic_tflops": tf, "mfma_frac": tf / FP32_MFMA_PEAK_TFLOPS}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +198,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=1, help="memory rows S (1 = reference-faithful pooled feature)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the S=64 decode / S=197 training variants")
     ap.add_argument("--train-steps", type=int, default=10, help="timed training steps of cfg3 (0 = skip)")
     ap.add_argument("--train-budget", type=float, default=240.0, help="seconds after which the training leg is abandoned")
     args = ap.parse_args()
@@ -259,6 +340,11 @@ def main():
         if rank == 0:
             out["train"] = train
 
+    if rank == 0 and world == 1 and not args.no_variants:
+        try:
+            out["variants"] = variants_bench(device)
+        except Exception as e:                       # secondary numbers must never cost the primary line
+            out["variants"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
