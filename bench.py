@@ -141,7 +141,25 @@ def variants_bench(device, steps=6, warmup=2):
     dt = (time.perf_counter() - t0) / steps
     out["decode_grid64"] = {"workload": f"CNN-Attn greedy decode over a 64x2048 feature grid (S=64), B={B}, len {LEN}",
                             "value": B / dt, "unit": "captions/s", "ms_per_step": dt * 1e3}
-    del model, feats
+    del model
+    # ---- the same grid through the soft-attention LSTM decoder (BASELINE.json configs[1] as worded; the reference has
+    #      no such model, so there is no parity target for it: checked against a PyTorch composition in the tests) ----
+    from models.softattn_model import SoftAttentionLSTMDecoder
+    torch.manual_seed(0)
+    sat = SoftAttentionLSTMDecoder(D, E, 512, 512, V).to(device).eval()
+    grid = feats.view(B, S, D)
+    for _ in range(warmup):
+        sat.caption_ids(grid, max_length=LEN)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sat.caption_ids(grid, max_length=LEN)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out["decode_softattn_lstm_grid64"] = {
+        "workload": f"soft-attention LSTM greedy decode over a 64x2048 feature grid, B={B}, len {LEN}, E=512, hidden 512, "
+                    f"attention 512, V={V}", "value": B / dt, "unit": "captions/s", "ms_per_step": dt * 1e3}
+    del sat, grid, feats
     # ---- training, S=197 tokens of width 768: Linear(768,E) per token, 3-layer decoder, loss, backward, Adam ----
     Bt, T, Lt, St, Dt = 512, 20, 3, 197, 768
     torch.manual_seed(0)

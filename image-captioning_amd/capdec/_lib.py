@@ -50,6 +50,11 @@ class RnnModel(Structure):
                 ("w_hh", c_void_p), ("b_ih", c_void_p), ("b_hh", c_void_p), ("fc2_w", c_void_p), ("fc2_b", c_void_p)]
 
 
+class SattModel(Structure):
+    _fields_ = [("E", c_int32), ("Hd", c_int32), ("A", c_int32), ("V", c_int32)] + \
+               [(n, c_void_p) for n in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "att_h_w", "att_h_b", "att_v", "fc2_w", "fc2_b")]
+
+
 class Probe(Structure):
     _fields_ = [("begin", POINTER(c_void_p)), ("end", POINTER(c_void_p)), ("n", c_int32)]
 
@@ -102,6 +107,10 @@ _SIGNATURES = {
     "capdec_tf_forward_logits": (c_int, [POINTER(TfModel), _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "capdec_rnn_decode_workspace_bytes": (c_size_t, [POINTER(RnnModel), c_int, c_int]),
     "capdec_rnn_greedy_decode": (c_int, [POINTER(RnnModel), _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
+    "capdec_additive_attention": (c_int, [_P, c_int64, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P]),
+    "capdec_satt_decode_workspace_bytes": (c_size_t, [POINTER(SattModel), c_int, c_int]),
+    "capdec_satt_greedy_decode": (c_int, [POINTER(SattModel), _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P,
+                                          c_size_t, _P, _P, _P]),
     "capdec_tf_beam_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int, c_int]),
     "capdec_tf_beam_search": (c_int, [POINTER(TfModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                       c_size_t, _P, _P, _P, _P, _P]),

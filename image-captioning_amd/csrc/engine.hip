@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __rest
                                                              int64_t* out_ids, int32_t* out_len, int32_t* dirty,
                                                              const float* __restrict__ emb,
                                                              const float* __restrict__ pe, int E, int V,
-                                                             float* __restrict__ x_next) {
+                                                             float* __restrict__ x_next, int64_t ldx_next = 0) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (b >= B) return;
@@ -73,13 +73,63 @@ __global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __rest
     if (x_next) {
         const f32x4* src = reinterpret_cast<const f32x4*>(emb + (int64_t)i * E);
         const f32x4* pp = pe ? reinterpret_cast<const f32x4*>(pe + (int64_t)(t + 1) * E) : nullptr;
-        f32x4* dst = reinterpret_cast<f32x4*>(x_next + (int64_t)b * E);
+        f32x4* dst = reinterpret_cast<f32x4*>(x_next + (int64_t)b * (ldx_next ? ldx_next : (int64_t)E));
         for (int c = lane; c < E / 4; c += 64) {
             f32x4 w = src[c];
             if (pp) w += pp[c];
             dst[c] = w;
         }
     }
+}
+
+// ---- additive (Bahdanau) attention over the memory rows of one sample -----------------------------------------
+//   e_s = sum_a v_a tanh(u_a + pf[s,a]),  alpha = softmax_s(e),  ctx = sum_s alpha_s enc[s,:]
+// One workgroup per sample.  The scores and the weights live in LDS; pf and enc are each read once, 16 bytes per lane.
+// (No counterpart in the reference: the soft-attention LSTM decoder of Show-Attend-Tell.)
+__global__ __launch_bounds__(256) void additive_attention_kernel(const float* __restrict__ u, int64_t ldu,
+                                                                 const float* __restrict__ pf,
+                                                                 const float* __restrict__ v,
+                                                                 const float* __restrict__ enc, int S, int A, int E,
+                                                                 float* __restrict__ ctx, int64_t ldctx,
+                                                                 float* __restrict__ alpha) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [S] scores, then [4][E] partial contexts
+    float* sc = lds;
+    float* part = lds + ((S + 3) / 4) * 4;
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* ub = u + (int64_t)b * ldu;
+    const float* pfb = pf + (int64_t)b * S * A;
+    const float* eb = enc + (int64_t)b * S * E;
+    for (int s = wave; s < S; s += 4) {
+        float e = 0.f;
+        for (int c = lane; c < A / 4; c += 64) {
+            const f32x4 p4 = *reinterpret_cast<const f32x4*>(pfb + (int64_t)s * A + 4 * c);
+            const f32x4 u4 = *reinterpret_cast<const f32x4*>(ub + 4 * c);
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(v + 4 * c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e += v4[k] * tanhf(u4[k] + p4[k]);
+        }
+        e = wave_sum(e);
+        if (lane == 0) sc[s] = e;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int s = lane; s < S; s += 64) mx = fmaxf(mx, sc[s]);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int s = lane; s < S; s += 64) sm += expf(sc[s] - mx);
+    sm = wave_sum(sm);
+    // each wavefront accumulates its share of the rows over all columns; the four partial contexts are summed in LDS
+    for (int c = lane; c < E / 4; c += 64) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = wave; s < S; s += 4)
+            acc += *reinterpret_cast<const f32x4*>(eb + (int64_t)s * E + 4 * c) * (expf(sc[s] - mx) / sm);
+        *reinterpret_cast<f32x4*>(part + wave * E + 4 * c) = acc;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < E; c += 256)
+        ctx[(int64_t)b * ldctx + c] = (part[c] + part[E + c]) + (part[2 * E + c] + part[3 * E + c]);
+    if (alpha)
+        for (int s = threadIdx.x; s < S; s += 256) alpha[(int64_t)b * S + s] = expf(sc[s] - mx) / sm;
 }
 
 // ---- beam search bookkeeping (transformer.py:177-244, cnnrnn_model.py:112-209) --------------------------------
@@ -884,6 +934,103 @@ int capdec_rnn_beam_search(const capdec_rnn_model* m, const float* x0, int B, in
     hipLaunchKernelGGL(beam_result_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.b.st[t_end & 1], ldtok, B, W, t_end,
                        max_len, eos, out_ids, out_len, out_scores);
     CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// Soft-attention LSTM decoder (additive attention over the memory rows feeding an LSTM cell).
+// The reference has no such model; this follows the Show-Attend-Tell decoder named by the project's goals.
+// =================================================================================================
+int capdec_additive_attention(const float* u, int64_t ldu, const float* pf, const float* v, const float* enc, int B, int S,
+                              int A, int E, float* ctx, int64_t ldctx, float* alpha, void* stream) {
+    CAPDEC_REQUIRE(u && pf && v && enc && ctx && B >= 0 && S >= 1 && S <= 4096 && A >= 4 && A % 4 == 0 && E >= 4 && E % 4 == 0);
+    CAPDEC_REQUIRE(ldu >= A && ldctx >= E && ldu % 4 == 0);
+    if (!capdec_aligned16(u) || !capdec_aligned16(pf) || !capdec_aligned16(v) || !capdec_aligned16(enc)) return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    const size_t smem = ((size_t)((S + 3) / 4) * 4 + 4 * (size_t)E) * sizeof(float);
+    CAPDEC_REQUIRE(smem <= 64 * 1024);
+    hipLaunchKernelGGL(additive_attention_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, u, ldu, pf, v, enc, S, A, E,
+                       ctx, ldctx, alpha);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+struct SattWs {
+    float *xcat, *emb0, *u, *h[2], *c[2];
+    float* pval; int32_t* pidx;
+    int32_t *tok, *done;
+};
+
+static size_t carve_satt(const capdec_satt_model* m, int B, int max_len, void* base, SattWs* w) {
+    Carver c(base);
+    SattWs d;
+    d.xcat = c.take<float>((size_t)B * 2 * m->E);
+    d.emb0 = c.take<float>((size_t)B * m->E);
+    d.u = c.take<float>((size_t)B * m->A);
+    for (int n = 0; n < 2; ++n) {
+        d.h[n] = c.take<float>((size_t)B * m->Hd);
+        d.c[n] = c.take<float>((size_t)B * m->Hd);
+    }
+    const size_t nt = (size_t)capdec_vocab_tiles(m->V);
+    d.pval = c.take<float>((size_t)B * nt);
+    d.pidx = c.take<int32_t>((size_t)B * nt);
+    d.tok = c.take<int32_t>((size_t)B * (max_len + 1));
+    d.done = c.take<int32_t>((size_t)B);
+    if (w) *w = d;
+    return c.off;
+}
+
+static int check_satt(const capdec_satt_model* m) {
+    CAPDEC_REQUIRE(m && m->E >= 4 && m->E % 4 == 0 && m->Hd >= 4 && m->Hd % 4 == 0 && m->A >= 4 && m->A % 4 == 0 && m->V >= 1);
+    CAPDEC_REQUIRE(m->emb && m->w_ih && m->w_hh && m->b_ih && m->b_hh && m->att_h_w && m->att_h_b && m->att_v && m->fc2_w &&
+                   m->fc2_b);
+    return 0;
+}
+
+size_t capdec_satt_decode_workspace_bytes(const capdec_satt_model* m, int B, int max_len) {
+    if (check_satt(m) != 0 || B < 0 || max_len < 1) return 0;
+    return carve_satt(m, B, max_len, nullptr, nullptr);
+}
+
+int capdec_satt_greedy_decode(const capdec_satt_model* m, const float* enc, const float* pf, const float* h0,
+                              const float* c0, int B, int S, int max_len, int sos, int eos, void* workspace,
+                              size_t workspace_bytes, int64_t* out_ids, int32_t* out_len, void* stream) {
+    CAPDEC_TRY(check_satt(m));
+    CAPDEC_REQUIRE(enc && pf && h0 && c0 && out_ids && out_len && B >= 0 && S >= 1 && max_len >= 1 && sos >= 0 && sos < m->V);
+    if (B == 0) return 0;
+    if (!workspace || !capdec_aligned16(workspace)) return CAPDEC_EALIGN;
+    SattWs w;
+    if (carve_satt(m, B, max_len, workspace, &w) > workspace_bytes) return CAPDEC_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->E, Hd = m->Hd, A = m->A, V = m->V;
+    const int64_t ldtok = max_len + 1;
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, out_ids, out_len,
+                       (int32_t*)nullptr, B, max_len, sos);
+    CAPDEC_LAUNCH_CHECK();
+    const int nt = capdec_vocab_tiles(V);
+    // <SOS> rows into the left half of the LSTM input rows (row stride 2E); the right half receives the context
+    CAPDEC_TRY(capdec_embed_pe(w.tok, 1, ldtok, m->emb, nullptr, 0, B, 1, E, V, w.emb0, stream));
+    if (hipMemcpy2DAsync(w.xcat, 2 * (size_t)E * sizeof(float), w.emb0, (size_t)E * sizeof(float), (size_t)E * sizeof(float),
+                         B, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return (int)hipGetLastError();
+    const float* h = h0;
+    const float* c = c0;
+    for (int t = 0; t < max_len; ++t) {
+        // u = att_h(h); attention context -> xcat[:, E:]
+        CAPDEC_TRY(linear(h, Hd, B, m->att_h_w, m->att_h_b, A, Hd, w.u, A, nullptr, 0, 0, s));
+        CAPDEC_TRY(capdec_additive_attention(w.u, A, pf, m->att_v, enc, B, S, A, E, w.xcat + E, 2 * E, nullptr, stream));
+        const int nx = t & 1;
+        CAPDEC_TRY(capdec_lstm_step(w.xcat, 2 * E, h, Hd, c, m->w_ih, m->w_hh, m->b_ih, m->b_hh, B, 2 * E, Hd, w.h[nx], Hd,
+                                    w.c[nx], nullptr, stream));
+        h = w.h[nx];
+        c = w.c[nx];
+        CAPDEC_TRY(capdec_vocab_argmax_partial(h, Hd, m->fc2_w, m->fc2_b, B, V, Hd, w.pval, w.pidx, stream));
+        const bool last = (t + 1 == max_len);
+        hipLaunchKernelGGL(greedy_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
+                           eos, w.tok, ldtok, w.done, out_ids, out_len, (int32_t*)nullptr, m->emb,
+                           (const float*)nullptr, E, V, last ? nullptr : w.xcat, (int64_t)2 * E);
+        CAPDEC_LAUNCH_CHECK();
+    }
     return 0;
 }
 

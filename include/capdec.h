@@ -327,6 +327,32 @@ int capdec_rnn_beam_search(const capdec_rnn_model* m, const float* x0, int B, in
                            int t_begin, int t_end, void* workspace, size_t workspace_bytes, int64_t* out_ids,
                            int32_t* out_len, float* out_scores, int32_t* n_unfinished, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Soft-attention LSTM decoder (additive attention over the memory rows feeding an LSTM cell).
+ * No counterpart in the reference (its "Attn" models are Transformer decoders); this is the Show-Attend-Tell
+ * style decoder named by the project's goals, so its results are checked against a PyTorch composition of the same
+ * formulas only.
+ *   e[b,s] = sum_a v[a] * tanh(u[b,a] + pf[b,s,a]) ; alpha = softmax_s(e) ; ctx[b,:] = sum_s alpha[b,s] * enc[b,s,:]
+ * u [B,A] (row stride ldu) = att_h(h) of the current state, pf [B,S,A] = att_f(enc) computed once per caption,
+ * enc [B,S,E]; ctx rows have stride ldctx (so they can land in the right half of the LSTM's [emb | ctx] input rows);
+ * alpha [B,S] is optional.
+ * ------------------------------------------------------------------------------------------ */
+int capdec_additive_attention(const float* u, int64_t ldu, const float* pf, const float* v, const float* enc, int B, int S,
+                              int A, int E, float* ctx, int64_t ldctx, float* alpha, void* stream);
+typedef struct capdec_satt_model {
+    int32_t E, Hd, A, V;
+    const float* emb;                          /* [V,E] */
+    const float *w_ih, *w_hh, *b_ih, *b_hh;    /* LSTM over the 2E-wide input [emb | ctx]: w_ih [4Hd,2E] */
+    const float *att_h_w, *att_h_b, *att_v;    /* [A,Hd], [A], [A] */
+    const float *fc2_w, *fc2_b;                /* [V,Hd], [V] */
+} capdec_satt_model;
+size_t capdec_satt_decode_workspace_bytes(const capdec_satt_model* m, int B, int max_len);
+/* Greedy decode with the bookkeeping of the reference's greedy loops (transformer.py:155-171): h0/c0 [B,Hd] initial
+ * state, per step: u = att_h(h), context, LSTM step on [emb | ctx], vocabulary arg-max, next embedding. */
+int capdec_satt_greedy_decode(const capdec_satt_model* m, const float* enc, const float* pf, const float* h0,
+                              const float* c0, int B, int S, int max_len, int sos, int eos, void* workspace,
+                              size_t workspace_bytes, int64_t* out_ids, int32_t* out_len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,14 @@ def main():
     wih, whh, bih, bhh = rnd(4 * Hd, Er), rnd(4 * Hd, Hd), rnd(4 * Hd), rnd(4 * Hd)
     mfma("lstm_step_kernel (gates + cell)", "B=1024,E=256,Hd=512", 2.0 * Br * (Er + Hd) * 4 * Hd,
          lambda: ops.lstm_step(xr, h0, c0, wih, whh, bih, bhh))
+    Bs, Ss, As = 1024, 64, 512
+    u, pfm, vv, encm = rnd(Bs, As), rnd(Bs * Ss, As), rnd(As), rnd(Bs * Ss, E)
+    ctx = torch.empty(Bs, E, device="cuda")
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    hbm("additive_attention_kernel (soft-attention LSTM step)", "B=1024,S=64,A=512,E=512", 1.0 * Bs * Ss * (As + E) * 4,
+        lambda: lib.capdec_additive_attention(u.data_ptr(), As, pfm.data_ptr(), vv.data_ptr(), encm.data_ptr(), Bs, Ss, As, E,
+                                              ctx.data_ptr(), E, None, st))
     print("| kernel | shape | algorithmic work | avg µs | achieved | of roof |")
     print("|---|---|---|---|---|---|")
     for name, shape, work, us, rate, frac in rows:
