@@ -155,3 +155,20 @@ def test_cfg5_yolocnn_attn_greedy_shard():
     check_greedy([got[r] for r in rows], sd, want_enc, H, 20)
     sub = _rows(*m.caption_ids(fd[512:544], max_length=20))
     assert sum(a != b for a, b in zip(sub, got[512:544])) <= 1
+
+
+def test_decode_batch_8192_is_batch_size_independent():
+    """The whole 8192-row batch of BASELINE configs[4] on one GPU (two memory rows): rows are independent, so a
+    64-row slice decoded alone must give the same ids, and a few rows must match the oracle."""
+    from gpu_util import plain_decoder
+    torch.manual_seed(0)
+    dec = plain_decoder(E, V, H, 2).cuda().eval()
+    sd = cpu_sd(dec)
+    g = torch.Generator().manual_seed(1234 + 5)
+    enc = torch.randn(8192, 2, E, generator=g)
+    got = _rows(*dec.greedy_ids(enc.cuda(), R.SOS, R.EOS, 20))
+    assert len(got) == 8192
+    rows = [0, 4097, 8191]
+    check_greedy([got[r] for r in rows], sd, enc[rows], H, 20)
+    sub = _rows(*dec.greedy_ids(enc[4096:4160].cuda(), R.SOS, R.EOS, 20))
+    assert sum(a != b for a, b in zip(sub, got[4096:4160])) <= 1
