@@ -40,6 +40,9 @@ class CaptionTrainer:
         self.lr, self.betas, self.eps, self.pad_idx = lr, betas, eps, pad_idx
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # gloo has no dependable device collectives: stage through the host there (tests and rehearsals on one GPU);
+        # RCCL ("nccl") reduces the device buffers in place
+        self.host_staged = self.world > 1 and dist.get_backend(process_group) == "gloo"
         self.t = 0
         self.rnn = getattr(model, "decoderRNN", None)          # CNN-RNN: the trainable module is the LSTM decoder
         core = self.rnn if self.rnn is not None else model
@@ -83,14 +86,38 @@ class CaptionTrainer:
                     off += (k + 3) // 4 * 4               # keep every tensor 16-byte aligned
                 self.segments.append((start, off))
             self.flat_p[off:].zero_()
+        # BatchNorm running statistics as views of one small buffer: DDP (broadcast_buffers=True, the default the
+        # reference gets from accelerate) re-broadcasts rank 0's buffers at the start of every forward pass
+        bn = core.batchnorm
+        C = bn.running_mean.numel()
+        self.flat_buf = torch.empty(2 * C, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            self.flat_buf[:C].copy_(bn.running_mean)
+            self.flat_buf[C:].copy_(bn.running_var)
+            bn.running_mean.data = self.flat_buf[:C]
+            bn.running_var.data = self.flat_buf[C:]
         if self.world > 1:
-            cdist.broadcast_(self.flat_p, src=0, group=self.pg)   # DDP starts from rank 0's weights
+            self._bcast(self.flat_p)                              # DDP starts from rank 0's weights
+            self._bcast(self.flat_buf)
 
     # -----------------------------------------------------------------------------------------
+    def _bcast(self, t):
+        if self.host_staged:
+            h = t.cpu()
+            dist.broadcast(h, src=0, group=self.pg)
+            t.copy_(h)
+        else:
+            cdist.broadcast_(t, src=0, group=self.pg)
+
     def _reduce_segment(self, i, works):
         if self.world > 1 and self.overlap:
             a, b = self.segments[i]
-            works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            if self.host_staged:
+                h = self.flat_g[a:b].cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+                self.flat_g[a:b].copy_(h)
+            else:
+                works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def step(self, feats, captions):
         """feats: precomputed backbone features [B,D]; captions [B,T+1] int64 (inputs [:, :-1], targets [:, 1:]).
@@ -99,6 +126,8 @@ class CaptionTrainer:
         model.train()
         self.t += 1
         self.flat_g.zero_()
+        if self.world > 1:
+            self._bcast(self.flat_buf)
         ids = captions[:, :-1].contiguous()
         tgt = captions[:, 1:].contiguous()
         if self.rnn is not None:
@@ -106,7 +135,12 @@ class CaptionTrainer:
         else:
             loss = self._tf_step(feats, ids, tgt)
         if self.world > 1 and not self.overlap:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.host_staged:
+                h = self.flat_g.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+                self.flat_g.copy_(h)
+            else:
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
         # ---- Adam over the flat buffers (DDP semantics: mean of the per-rank gradients) ----
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1],
                       self.eps, grad_scale=1.0 / self.world)

@@ -1,0 +1,67 @@
+"""Data-parallel training semantics on the GPU: two ranks (sharing GPU 0, gloo with host-staged collectives) against
+a CPU simulation of what the reference gets from accelerate/DDP (train.py:176,224-226,261): every rank starts from
+rank 0's weights, computes the loss mean over its OWN non-PAD targets with its OWN BatchNorm batch statistics, the
+gradients are averaged over ranks, Adam steps on the average; the BatchNorm running buffers follow rank 0."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import decoder_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_training_matches_ddp_semantics(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_train_worker import batch
+    from models.vitcnnattn_model import VITCNNAttentionModel
+    out = str(tmp_path / "dp.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "tests", "dist_train_worker.py"), out]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-3000:]
+    got = np.load(out)
+    # CPU simulation
+    H = 4
+    torch.manual_seed(7)                                         # rank 0's seed
+    m = VITCNNAttentionModel(64, 90, H, 2, dropout=0.0)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k and k != "positional_encoding.pe")
+          for k, v in m.state_dict().items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    batches = [batch(r) for r in range(2)]
+    ref_losses = [[], []]
+    for _ in range(2):
+        grads = [torch.zeros_like(p) for p in params]
+        new0 = None
+        for r, (feats, caps) in enumerate(batches):
+            enc, new = R.head_pair(sd, feats, "fc_vit", 1000, training=True)
+            loss = R.caption_loss(R.decoder_forward(sd, enc, caps[:, :-1], H), caps[:, 1:])
+            gs = torch.autograd.grad(loss, params, allow_unused=True)
+            for acc, gr in zip(grads, gs):
+                if gr is not None:
+                    acc += gr / 2
+            ref_losses[r].append(float(loss.detach()))
+            if r == 0:
+                new0 = new
+        for p, gr in zip(params, grads):
+            p.grad = gr
+        opt.step()
+        for k, v in new0.items():                                # buffers follow rank 0
+            sd[k] = v
+    for r in range(2):
+        for a, b in zip(got["loss_r%d" % r], ref_losses[r]):
+            assert abs(a - b) <= 1e-4 * abs(b), (r, got["loss_r%d" % r], ref_losses[r])
+    lr, steps = 1e-3, 2
+    for k, v in sd.items():
+        if v.is_floating_point():
+            d = np.abs(got["sd__" + k].astype(np.float64) - v.detach().double().numpy())
+            assert d.max() <= 2.2 * lr * steps, (k, d.max())
+            if not k.endswith(("W_k.bias", "fc_vit.bias", "fc_cnn.bias", "batchnorm.running_mean")):
+                assert d.mean() <= 3e-6, (k, d.mean())
