@@ -296,7 +296,7 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ P, const floa
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
 template <int WM, int WI, int WJ, int BK, bool VEC, bool TP, bool TQ, int KG>
-__global__ __launch_bounds__(128 * WM * KG) void gemm_kernel(GemmKArgs args) {
+__global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3 : 1) void gemm_kernel(GemmKArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int z, tile_i, tile_j;
     if (!tile_of_block(args.map, blockIdx.x, z, tile_i, tile_j)) return;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(128 * WM * KG) void gemm_kernel(GemmKArgs args) {
 // ---- vocabulary projection with lane-local reductions over the vocabulary axis -------------------
 // P = W [V,K] (i = vocabulary id), Q = x [M,K] (j = row).  MODE 0: arg-max; MODE 1: (max, sum exp).
 template <int WI, int WJ, int BK, bool VEC, int MODE>
-__global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restrict__ W, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 5) void vocab_reduce_kernel(const float* __restrict__ W, const float* __restrict__ x,
                                                            int64_t ldx, const float* __restrict__ bias, int V, int M,
                                                            int K, float* __restrict__ out_a, void* __restrict__ out_b,
                                                            int ntiles, TileMap map) {
