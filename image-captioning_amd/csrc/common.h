@@ -58,7 +58,10 @@ int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int 
                        const capdec_gemm_extra* extra = nullptr);
 int capdec_launch_layernorm_rows(const float* x, const float* add, int add_div, const int32_t* add_map,
                                  const float* gamma, const float* beta, float eps, int Mcap, int E, float* y,
-                                 const int32_t* rows_dev, hipStream_t s);
+                                 const int32_t* rows_dev, hipStream_t s, const float* gamma2 = nullptr,
+                                 const float* beta2 = nullptr, const float* add2 = nullptr, int add2_div = 1,
+                                 const int32_t* add2_map = nullptr);
+// (gamma2 != NULL: y = LN2(LN1(x + add) + add2[add2_map[row] / add2_div]) in one pass over the row)
 int capdec_launch_attention_rows(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
                                  int64_t ldv, int64_t sv, float* out, int64_t ldo, int Rcap, int H, int Tk, int dk,
                                  int causal, const int32_t* ids, int64_t ldid, const int32_t* row_map, int map_div,

@@ -569,12 +569,13 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
             CAPDEC_TRY(capdec_launch_attention_rows(w.q, E, kc, E, (int64_t)max_len * E, vc, E, (int64_t)max_len * E,
                                                     w.ao, E, Mcap, H, t + 1, dk, 1, w.tok, ldtok, map, max_len, rows, s));
             CAPDEC_TRY(linear_rows(w.ao, Mcap, ly.self_attn.wo, ly.self_attn.bo, E, w.y, w.x, 0, rows, s));
-            CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, Mcap, E, w.x1,
-                                                    rows, s));
             if (s1) {
-                CAPDEC_TRY(capdec_launch_layernorm_rows(w.x1, w.cc + l * BE, max_len, map, ly.n2_g, ly.n2_b, 1e-5f,
-                                                        Mcap, E, w.x2, rows, s));
+                // norm1 and norm2 in one pass: the cross-attention sub-layer is the per-sample constant cc
+                CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, Mcap, E, w.x2,
+                                                        rows, s, ly.n2_g, ly.n2_b, w.cc + l * BE, max_len, map));
             } else {
+                CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, Mcap, E, w.x1,
+                                                        rows, s));
                 CAPDEC_TRY(linear_rows(w.x1, Mcap, ly.cross_attn.wq, ly.cross_attn.bq, E, w.q, nullptr, 0, rows, s));
                 CAPDEC_TRY(capdec_launch_attention_rows(w.q, E, w.ck + (size_t)l * BE * S, E, (int64_t)S * E,
                                                         w.cv + (size_t)l * BE * S, E, (int64_t)S * E, w.ao, E, Mcap, H, S,

@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
                                                             float* __restrict__ y, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out,
                                                             const int32_t* __restrict__ add_map,
-                                                            const int32_t* __restrict__ rows_dev) {
+                                                            const int32_t* __restrict__ rows_dev,
+                                                            const float* __restrict__ gamma2 = nullptr,
+                                                            const float* __restrict__ beta2 = nullptr,
+                                                            const float* __restrict__ add2 = nullptr, int add2_div = 1,
+                                                            const int32_t* __restrict__ add2_map = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M || (rows_dev && row >= rows_dev[0])) return;
@@ -95,6 +99,40 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     f32x4* yr = reinterpret_cast<f32x4*>(y + (int64_t)row * E);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
     const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+    if (gamma2) {
+        // second normalisation on the same row, still in registers: y = LN2(LN1(x + add) + add2); the intermediate is
+        // rounded exactly as if it had been stored, so the result equals two separate launches bit for bit
+        const int arow2 = (add2_map ? add2_map[row] : row) / add2_div;
+        const f32x4* a2 = reinterpret_cast<const f32x4*>(add2 + (int64_t)arow2 * E);
+        float s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nv) {
+                v[u] = (v[u] * rstd * g4[c] + b4[c]) + a2[c];
+                s2 += v[u][0] + v[u][1] + v[u][2] + v[u][3];
+            }
+        }
+        const float mean2 = wave_sum(s2) / (float)E;
+        float q2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nv) {
+                v[u] -= mean2;
+                q2 += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+            }
+        }
+        const float rstd2 = 1.0f / sqrtf(wave_sum(q2) / (float)E + eps);
+        const f32x4* g24 = reinterpret_cast<const f32x4*>(gamma2);
+        const f32x4* b24 = reinterpret_cast<const f32x4*>(beta2);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nv) yr[c] = v[u] * rstd2 * g24[c] + b24[c];
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
@@ -302,11 +340,13 @@ __global__ __launch_bounds__(256) void bn_train_kernel(const float* __restrict__
 // ---- row-list forms used by the decode engine (device-side row count, explicit (sample, position) per row) ----
 int capdec_launch_layernorm_rows(const float* x, const float* add, int add_div, const int32_t* add_map,
                                  const float* gamma, const float* beta, float eps, int Mcap, int E, float* y,
-                                 const int32_t* rows_dev, hipStream_t s) {
+                                 const int32_t* rows_dev, hipStream_t s, const float* gamma2, const float* beta2,
+                                 const float* add2, int add2_div, const int32_t* add2_map) {
     if (Mcap == 0) return 0;
 #define CAPDEC_CALL(NV_)                                                                                          \
     hipLaunchKernelGGL(add_layernorm_kernel<NV_>, dim3((Mcap + 3) / 4), dim3(256), 0, s, x, add, add ? add_div : 1, \
-                       gamma, beta, eps, Mcap, E, y, (float*)nullptr, (float*)nullptr, add_map, rows_dev)
+                       gamma, beta, eps, Mcap, E, y, (float*)nullptr, (float*)nullptr, add_map, rows_dev, gamma2,   \
+                       beta2, add2, add2_div, add2_map)
     CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
