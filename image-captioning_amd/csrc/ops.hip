@@ -255,6 +255,89 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     if (live && lane == 0 && a.lse) a.lse[idx] = mx + logf(sum);
 }
 
+// Short sequences without a row list (teacher-forced forward, full-prefix decode): one workgroup per (b,h) stages
+// that head's K and V once in LDS (rows padded to dk+16 floats: the 16-keys-by-4-parts sweep then touches 64
+// distinct banks per 16 lanes) and its four wavefronts walk the query rows.  Same arithmetic, row by row, as
+// attention_kernel.
+template <int NM>
+__global__ __launch_bounds__(256) void attention_short_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dk = a.dk, LD = dk + 16, Tq = a.Tq, Tk = a.Tk;
+    float* Ks = lds;
+    float* Vs = Ks + Tk * LD;
+    float* scs = Vs + Tk * LD;             // [4][Tk] score rows
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int nv = dk / 4;
+    for (int idx = threadIdx.x; idx < Tk * nv; idx += 256) {
+        const int r = idx / nv, c = idx - r * nv;
+        *reinterpret_cast<f32x4*>(&Ks[r * LD + 4 * c]) =
+            *reinterpret_cast<const f32x4*>(a.k + (int64_t)b * a.sk + (int64_t)r * a.ldk + (int64_t)h * dk + 4 * c);
+        *reinterpret_cast<f32x4*>(&Vs[r * LD + 4 * c]) =
+            *reinterpret_cast<const f32x4*>(a.v + (int64_t)b * a.sv + (int64_t)r * a.ldv + (int64_t)h * dk + 4 * c);
+    }
+    __syncthreads();
+    float* sc = scs + wave * Tk;
+    const float scale = sqrtf((float)dk);
+    const int part = lane & 3, kl = lane >> 2;
+    const int lpv = dk / 4, grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
+    for (int i = wave; i < Tq; i += 4) {
+        const int64_t qrow = (int64_t)b * Tq + i;
+        const bool pad_row = a.ids && a.ids[(int64_t)b * a.ldid + i] == 0;
+        int nkeys = Tk;
+        if (a.causal && !pad_row) {
+            nkeys = i + a.causal_off + 1;
+            nkeys = nkeys < 1 ? 1 : (nkeys > Tk ? Tk : nkeys);
+        }
+        float mx = -1e9f, sum = (float)nkeys;
+        if (!pad_row) {
+            const float* qp = a.q + qrow * a.ldq + (int64_t)h * dk + 4 * part;
+            f32x4 qreg[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) qreg[m] = *reinterpret_cast<const f32x4*>(qp + 16 * m);
+            for (int j0 = 0; j0 < nkeys; j0 += 16) {
+                const int j = j0 + kl;
+                float d = 0.f;
+                if (j < nkeys) {
+                    const float* kp = Ks + j * LD + 4 * part;
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 16 * m);
+                        d += qreg[m][0] * kk[0] + qreg[m][1] * kk[1] + qreg[m][2] * kk[2] + qreg[m][3] * kk[3];
+                    }
+                }
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                if (part == 0 && j < nkeys) sc[j] = d / scale;
+            }
+            // LDS serves one wavefront's accesses in order: the scores above are visible to its other lanes
+            float m = -INFINITY;
+            for (int j = lane; j < nkeys; j += 64) m = fmaxf(m, sc[j]);
+            mx = wave_max(m);
+            float s = 0.f;
+            for (int j = lane; j < nkeys; j += 64) {
+                const float e = expf(sc[j] - mx);
+                sc[j] = e;
+                s += e;
+            }
+            sum = wave_sum(s);
+        } else {
+            for (int j = lane; j < nkeys; j += 64) sc[j] = 1.f;      // uniform over all Tk keys
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = grp; j < nkeys; j += ngrp)
+            acc += *reinterpret_cast<const f32x4*>(Vs + j * LD + 4 * dl) * (sc[j] / sum);
+        for (int o = lpv; o < 64; o <<= 1) {
+            acc[0] += __shfl_xor(acc[0], o, 64);
+            acc[1] += __shfl_xor(acc[1], o, 64);
+            acc[2] += __shfl_xor(acc[2], o, 64);
+            acc[3] += __shfl_xor(acc[3], o, 64);
+        }
+        if (grp == 0) *reinterpret_cast<f32x4*>(a.out + qrow * a.ldo + (int64_t)h * dk + 4 * dl) = acc;
+        if (lane == 0 && a.lse) a.lse[((int64_t)b * a.H + h) * Tq + i] = mx + logf(sum);
+    }
+}
+
 // ---- BatchNorm1d on [B, C] ----------------------------------------------------------------------
 // eval: fold the running statistics into a per-column scale/shift for a GEMM epilogue
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -430,6 +513,16 @@ int capdec_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, i
     if (B == 0) return 0;
     AttnArgs a{q, ldq, k, ldk, sk, v, ldv, sv, out, ldo, B, H, Tq, Tk, dk, causal, causal_off, ids, ldid, lse,
                nullptr, 1, nullptr};
+    // several query rows per head and a short key list: stage K/V of each (b,h) once in LDS
+    const size_t short_lds = ((size_t)2 * Tk * (dk + 16) + 4 * (size_t)Tk) * sizeof(float);
+    if (Tq >= 4 && Tk <= 64 && short_lds <= 64 * 1024) {
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attention_short_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), short_lds, (hipStream_t)stream, a)
+        CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
+#undef CAPDEC_CALL
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
     const long total = (long)B * H * Tq;
 #define CAPDEC_CALL(NM_)                                                                                          \
     hipLaunchKernelGGL(attention_kernel<NM_>, dim3((unsigned)((total + 3) / 4)), dim3(256), 4 * Tk * sizeof(float), \
