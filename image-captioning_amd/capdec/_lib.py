@@ -114,6 +114,9 @@ _SIGNATURES = {
     "capdec_tf_beam_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int, c_int]),
     "capdec_tf_beam_search": (c_int, [POINTER(TfModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                       c_size_t, _P, _P, _P, _P, _P]),
+    "capdec_tf_beam_cached_workspace_bytes": (c_size_t, [POINTER(TfModel), c_int, c_int, c_int, c_int]),
+    "capdec_tf_beam_search_cached": (c_int, [POINTER(TfModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             _P, c_size_t, _P, _P, _P, _P, _P, _P]),
     "capdec_rnn_beam_workspace_bytes": (c_size_t, [POINTER(RnnModel), c_int, c_int, c_int]),
     "capdec_rnn_beam_search": (c_int, [POINTER(RnnModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                        c_size_t, _P, _P, _P, _P, _P]),

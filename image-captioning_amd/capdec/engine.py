@@ -228,10 +228,31 @@ def _beam_loop(run, B, W, max_length, dev, return_scores):
     return out_ids.cpu(), out_len.cpu()
 
 
-def tf_beam_ids(dec, enc, beam_width, max_length, sos, eos, return_scores=False):
+def _tf_beam_exact(lib, ref, enc, W, max_length, sos, eos, return_scores):
+    B, S, _ = enc.shape
+    dev = enc.device
+    nbytes = lib.capdec_tf_beam_workspace_bytes(ctypes.byref(ref.c), B, W, S, max_length)
+    if nbytes == 0:
+        raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
+    ws = _workspace(nbytes, dev)
+
+    def run(t0, t1, out_ids, out_len, scores, left):
+        _lib.check(lib.capdec_tf_beam_search(ctypes.byref(ref.c), enc.data_ptr(), B, W, S, max_length, sos, eos, t0, t1,
+                                             ws.data_ptr(), ws.numel(), out_ids.data_ptr(), out_len.data_ptr(),
+                                             scores.data_ptr(), left.data_ptr(), _stream()), "capdec_tf_beam_search")
+
+    return _beam_loop(run, B, W, max_length, dev, return_scores)
+
+
+def tf_beam_ids(dec, enc, beam_width, max_length, sos, eos, return_scores=False, exact=False):
     """Beam search of a DecoderTransformer (reference transformer.py:177-244).  enc [B,S,E] fp32 on the GPU, one
     memory per sample.  Returns CPU (ids int64 [B,max_length] padded with -1, lengths int32 [B][, scores [B,W]]):
-    the best hypothesis of every sample, without <SOS>, cut at its first <EOS>."""
+    the best hypothesis of every sample, without <SOS>, cut at its first <EOS>.
+
+    By default the KV-cached form runs first; samples in which a hypothesis received a <PAD> token (whose query row
+    the reference lets attend uniformly over the current length: no cache can hold that) are then redone with the
+    full-prefix form, so the result is the reference's in every case.  ``exact=True`` uses the full-prefix form for
+    every sample."""
     lib = _lib.load()
     if not enc.is_cuda or enc.dtype != torch.float32:
         raise RuntimeError("capdec: enc must be an fp32 tensor on the GPU (HIP); there is no CPU path")
@@ -247,17 +268,28 @@ def tf_beam_ids(dec, enc, beam_width, max_length, sos, eos, return_scores=False)
         return torch.empty((0, max_length), dtype=torch.int64), torch.empty((0,), dtype=torch.int32)
     dev = enc.device
     with torch.cuda.device(dev):
-        nbytes = lib.capdec_tf_beam_workspace_bytes(ctypes.byref(ref.c), B, W, S, max_length)
+        if exact:
+            return _tf_beam_exact(lib, ref, enc, W, max_length, sos, eos, return_scores)
+        nbytes = lib.capdec_tf_beam_cached_workspace_bytes(ctypes.byref(ref.c), B, W, S, max_length)
         if nbytes == 0:
             raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
         ws = _workspace(nbytes, dev)
+        pad_seen = torch.zeros((B,), dtype=torch.int32, device=dev)
 
         def run(t0, t1, out_ids, out_len, scores, left):
-            _lib.check(lib.capdec_tf_beam_search(ctypes.byref(ref.c), enc.data_ptr(), B, W, S, max_length, sos, eos, t0, t1,
-                                                 ws.data_ptr(), ws.numel(), out_ids.data_ptr(), out_len.data_ptr(),
-                                                 scores.data_ptr(), left.data_ptr(), _stream()), "capdec_tf_beam_search")
+            _lib.check(lib.capdec_tf_beam_search_cached(ctypes.byref(ref.c), enc.data_ptr(), B, W, S, max_length, sos, eos,
+                                                        t0, t1, ws.data_ptr(), ws.numel(), out_ids.data_ptr(),
+                                                        out_len.data_ptr(), scores.data_ptr(), left.data_ptr(),
+                                                        pad_seen.data_ptr(), _stream()), "capdec_tf_beam_search_cached")
 
-        return _beam_loop(run, B, W, max_length, dev, return_scores)
+        res = _beam_loop(run, B, W, max_length, dev, True)
+        rows = torch.nonzero(pad_seen.cpu(), as_tuple=False).flatten()
+        if rows.numel():
+            sub = enc.index_select(0, rows.to(dev)).contiguous()
+            fix = _tf_beam_exact(lib, ref, sub, W, max_length, sos, eos, True)
+            for dst, src in zip(res, fix):
+                dst[rows] = src
+        return res if return_scores else res[:2]
 
 
 def rnn_beam_ids(rnn, x0, beam_width, max_length, sos, eos, return_scores=False):

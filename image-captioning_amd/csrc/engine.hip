@@ -200,7 +200,8 @@ __global__ void beam_init_kernel(BeamState st, int64_t ldtok, int N, int sos) {
 // that still have an unfinished hypothesis.
 __global__ void beam_select_kernel(int step, int B, int W, int eos, BeamState cur, BeamState nxt, int64_t ldtok,
                                    const float* __restrict__ top_lp, const int32_t* __restrict__ top_id,
-                                   int32_t* __restrict__ parent, int32_t* __restrict__ n_unfinished) {
+                                   int32_t* __restrict__ parent, int32_t* __restrict__ n_unfinished,
+                                   int32_t* __restrict__ pad_seen = nullptr) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float cand[BEAM_MAX_W * BEAM_MAX_W];
@@ -233,6 +234,7 @@ __global__ void beam_select_kernel(int step, int B, int W, int eos, BeamState cu
         const int fin = (cur.done[src] != 0 || tokn == eos) ? 1 : 0;
         nxt.done[dst] = fin;
         parent[dst] = src;
+        if (pad_seen && tokn == 0) pad_seen[b] = 1;      // a <PAD> query row attends uniformly: no cache can hold that
         every = every && fin;
     }
     if (!every) atomicAdd(n_unfinished, 1);
@@ -248,6 +250,21 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src + (int64_t)from * D);
     f32x4* d4 = reinterpret_cast<f32x4*>(dst + (int64_t)row * D);
     for (int c = lane; c < D / 4; c += 64) d4[c] = s4[c];
+}
+
+// Key/value caches follow their hypotheses: dst[a][n][p][:] = src[a][parent[n]][p][:] for p < len, for every cache
+// array a (layer x {K,V}) of [N][max_len][E] floats.  One wavefront per (n, p) row.
+__global__ __launch_bounds__(256) void beam_cache_gather_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                const int32_t* __restrict__ parent, int N, int len,
+                                                                int max_len, int E) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= (long)N * len) return;
+    const int n = (int)(row / len), p = (int)(row - (long)n * len);
+    const size_t arr = (size_t)blockIdx.y * N * max_len * E;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + arr + ((size_t)parent[n] * max_len + p) * E);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst + arr + ((size_t)n * max_len + p) * E);
+    for (int c = lane; c < E / 4; c += 64) d4[c] = s4[c];
 }
 
 // Best hypothesis of every sample without <SOS>, cut at its first <EOS> (transformer.py:233-241)
@@ -799,14 +816,14 @@ static void carve_beam_bufs(Carver& c, int N, int W, int V, int max_len, BeamBuf
 }
 
 static int beam_pick(const BeamBufs& d, int t, int B, int W, int V, int eos, int64_t ldtok, int32_t* n_unfinished,
-                     hipStream_t s) {
+                     hipStream_t s, int32_t* pad_seen = nullptr) {
     const int N = B * W;
     hipLaunchKernelGGL(beam_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d.logits, (int64_t)V, N, V, W, d.top_lp,
                        d.top_id);
     CAPDEC_LAUNCH_CHECK();
     if (hipMemsetAsync(n_unfinished, 0, sizeof(int32_t), s) != hipSuccess) return (int)hipGetLastError();
     hipLaunchKernelGGL(beam_select_kernel, dim3((B + 63) / 64), dim3(64), 0, s, t, B, W, eos, d.st[t & 1],
-                       d.st[(t + 1) & 1], ldtok, d.top_lp, d.top_id, d.parent, n_unfinished);
+                       d.st[(t + 1) & 1], ldtok, d.top_lp, d.top_id, d.parent, n_unfinished, pad_seen);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -864,6 +881,127 @@ int capdec_tf_beam_search(const capdec_tf_model* m, const float* enc, int B, int
         CAPDEC_TRY(linear(w.f.f.X + (size_t)(T - 1) * E, (int64_t)T * E, N, m->fc2_w, m->fc2_b, V, E, w.b.logits, V,
                           nullptr, 0, 0, s));
         CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, n_unfinished, s));
+    }
+    hipLaunchKernelGGL(beam_result_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.b.st[t_end & 1], ldtok, B, W, t_end,
+                       max_len, eos, out_ids, out_len, out_scores);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- KV-cached beam search: one new position per hypothesis and step; the caches are re-gathered after every
+// selection so that each surviving hypothesis owns its parent's keys and values.  Samples in which a <PAD> token is
+// generated are reported in pad_seen: the reference lets a <PAD> query row attend uniformly over the CURRENT length,
+// which changes that position's output at every later step, so those samples must be redone with the full-prefix form.
+struct TfBeamCacheWs {
+    float *x, *y, *x2, *x1, *q, *ao, *hb;     // [N][E]
+    float *cc, *ck, *cv, *encx;
+    float* cache[2];                          // each [L][2][N][max_len][E]
+    BeamBufs b;
+};
+
+static size_t carve_tf_beam_cached(const capdec_tf_model* m, int B, int W, int S, int max_len, void* base,
+                                   TfBeamCacheWs* w) {
+    const int N = B * W;
+    const size_t NE = (size_t)N * m->E;
+    Carver c(base);
+    TfBeamCacheWs d;
+    d.x = c.take<float>(NE); d.y = c.take<float>(NE); d.x2 = c.take<float>(NE); d.x1 = c.take<float>(NE);
+    d.q = c.take<float>(NE); d.ao = c.take<float>(NE); d.hb = c.take<float>(NE);
+    d.cc = c.take<float>(S == 1 ? (size_t)m->L * B * m->E : 1);
+    d.ck = c.take<float>(S == 1 ? 1 : (size_t)m->L * NE * S);
+    d.cv = c.take<float>(S == 1 ? 1 : (size_t)m->L * NE * S);
+    d.encx = c.take<float>(S == 1 ? 1 : NE * S);
+    for (int n = 0; n < 2; ++n) d.cache[n] = c.take<float>((size_t)m->L * 2 * NE * max_len);
+    carve_beam_bufs(c, N, W, m->V, max_len, &d.b);
+    if (w) *w = d;
+    return c.off;
+}
+
+size_t capdec_tf_beam_cached_workspace_bytes(const capdec_tf_model* m, int B, int W, int S, int max_len) {
+    if (check_model(m) != 0 || B < 0 || W < 1 || W > BEAM_MAX_W || S < 1 || max_len < 1) return 0;
+    return carve_tf_beam_cached(m, B, W, S, max_len, nullptr, nullptr);
+}
+
+int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int B, int W, int S, int max_len, int sos,
+                                 int eos, int t_begin, int t_end, void* workspace, size_t workspace_bytes,
+                                 int64_t* out_ids, int32_t* out_len, float* out_scores, int32_t* n_unfinished,
+                                 int32_t* pad_seen, void* stream) {
+    CAPDEC_TRY(check_model(m));
+    CAPDEC_REQUIRE(enc && out_ids && out_len && n_unfinished && pad_seen && B >= 0 && W >= 1 && W <= BEAM_MAX_W && S >= 1 &&
+                   S <= 2048);
+    CAPDEC_REQUIRE(max_len >= 1 && max_len <= m->max_pos && sos >= 0 && sos < m->V && m->V >= W);
+    CAPDEC_REQUIRE(0 <= t_begin && t_begin < t_end && t_end <= max_len);
+    if (B == 0) return 0;
+    if (!workspace || !capdec_aligned16(workspace) || !capdec_aligned16(enc)) return CAPDEC_EALIGN;
+    TfBeamCacheWs w;
+    if (carve_tf_beam_cached(m, B, W, S, max_len, workspace, &w) > workspace_bytes) return CAPDEC_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->E, V = m->V, H = m->H, L = m->L, dk = E / H, N = B * W;
+    const size_t NE = (size_t)N * E, BE = (size_t)B * E;
+    const int64_t ldtok = max_len + 1, cstride = (int64_t)max_len * E;
+    const bool s1 = S == 1;
+    if (t_begin == 0) {
+        hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos);
+        CAPDEC_LAUNCH_CHECK();
+        if (hipMemsetAsync(pad_seen, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return (int)hipGetLastError();
+        if (s1) {
+            for (int l = 0; l < L; ++l) {
+                const capdec_attn_w& a = m->layers[l].cross_attn;
+                CAPDEC_TRY(linear(enc, E, B, a.wv, a.bv, E, E, w.ao, E, nullptr, 0, 0, s));
+                CAPDEC_TRY(linear(w.ao, E, B, a.wo, a.bo, E, E, w.cc + l * BE, E, nullptr, 0, 0, s));
+            }
+        } else {
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, enc, (const int32_t*)nullptr, W, N,
+                               S * E, w.encx);
+            CAPDEC_LAUNCH_CHECK();
+            CAPDEC_TRY(project_memory(m, w.encx, N, S, w.ck, w.cv, s));
+        }
+        CAPDEC_TRY(capdec_embed_pe(w.b.st[0].tok, 1, ldtok, m->emb, m->pe, 0, N, 1, E, V, w.x, stream));
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+        float* cur = w.cache[t & 1];
+        float* nxt = w.cache[(t + 1) & 1];
+        for (int l = 0; l < L; ++l) {
+            const capdec_tf_layer& ly = m->layers[l];
+            float* kc = cur + (size_t)(2 * l) * NE * max_len;
+            float* vc = cur + (size_t)(2 * l + 1) * NE * max_len;
+            // q, and k/v of the new position straight into row t of every hypothesis' cache
+            capdec_gemm_group g[3];
+            g[0] = linear_group(w.x, E, N, ly.self_attn.wq, ly.self_attn.bq, E, w.q, E);
+            g[1] = linear_group(w.x, E, N, ly.self_attn.wk, ly.self_attn.bk, E, kc + (size_t)t * E, cstride);
+            g[2] = linear_group(w.x, E, N, ly.self_attn.wv, ly.self_attn.bv, E, vc + (size_t)t * E, cstride);
+            g[0].ldq = g[1].ldq = g[2].ldq = E;
+            CAPDEC_TRY(capdec_launch_gemm(g, 3, E, 0, s));
+            CAPDEC_TRY(capdec_attention(w.q, E, kc, E, cstride, vc, E, cstride, w.ao, E, N, H, 1, t + 1, dk, 0, 0, nullptr,
+                                        0, nullptr, stream));
+            CAPDEC_TRY(linear(w.ao, E, N, ly.self_attn.wo, ly.self_attn.bo, E, E, w.y, E, w.x, E, 0, s));
+            if (s1) {
+                CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, N, E, w.x2, nullptr,
+                                                        s, ly.n2_g, ly.n2_b, w.cc + l * BE, W, nullptr));
+            } else {
+                CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, N, E, w.x1, nullptr,
+                                                        s));
+                CAPDEC_TRY(linear(w.x1, E, N, ly.cross_attn.wq, ly.cross_attn.bq, E, E, w.q, E, nullptr, 0, 0, s));
+                CAPDEC_TRY(capdec_attention(w.q, E, w.ck + (size_t)l * NE * S, E, (int64_t)S * E, w.cv + (size_t)l * NE * S, E,
+                                            (int64_t)S * E, w.ao, E, N, H, 1, S, dk, 0, 0, nullptr, 0, nullptr, stream));
+                CAPDEC_TRY(linear(w.ao, E, N, ly.cross_attn.wo, ly.cross_attn.bo, E, E, w.y, E, w.x1, E, 0, s));
+                CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n2_g, ly.n2_b, 1e-5f, N, E, w.x2, nullptr,
+                                                        s));
+            }
+            CAPDEC_TRY(linear(w.x2, E, N, ly.ff_w1, ly.ff_b1, E, E, w.hb, E, nullptr, 0, CAPDEC_GEMM_RELU, s));
+            CAPDEC_TRY(linear(w.hb, E, N, ly.ff_w2, ly.ff_b2, E, E, w.y, E, w.x2, E, 0, s));
+            CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n3_g, ly.n3_b, 1e-5f, N, E, w.x, nullptr, s));
+        }
+        CAPDEC_TRY(linear(w.x, E, N, m->fc2_w, m->fc2_b, V, E, w.b.logits, V, nullptr, 0, 0, s));
+        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, n_unfinished, s, pad_seen));
+        if (t + 1 < max_len) {
+            const long rows = (long)N * (t + 1);
+            hipLaunchKernelGGL(beam_cache_gather_kernel, dim3((unsigned)((rows + 3) / 4), 2 * L), dim3(256), 0, s, cur, nxt,
+                               w.b.parent, N, t + 1, max_len, E);
+            CAPDEC_LAUNCH_CHECK();
+            CAPDEC_TRY(capdec_embed_pe(w.b.st[(t + 1) & 1].tok + (t + 1), 1, ldtok, m->emb, m->pe, t + 1, N, 1, E, V, w.x,
+                                       stream));
+        }
     }
     hipLaunchKernelGGL(beam_result_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.b.st[t_end & 1], ldtok, B, W, t_end,
                        max_len, eos, out_ids, out_len, out_scores);

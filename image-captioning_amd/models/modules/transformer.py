@@ -121,10 +121,12 @@ class DecoderTransformer(ABC, nn.Module):
         return [" ".join(itos[i] for i in row) for row in engine.ids_to_lists(ids, lengths)]
 
     # -- beam search ---------------------------------------------------------------------------
-    def beam_ids(self, enc_output, sos, eos, beam_width, max_length, return_scores=False):
+    def beam_ids(self, enc_output, sos, eos, beam_width, max_length, return_scores=False, exact=False):
         """Best hypothesis per sample as token ids (ids int64 [B,max_length] padded with -1, lengths [B]) on the CPU.
-        enc_output [B,S,E]: one memory per sample."""
-        return engine.tf_beam_ids(self, enc_output, beam_width, max_length, sos, eos, return_scores=return_scores)
+        enc_output [B,S,E]: one memory per sample.  ``exact=True`` forces the full-prefix recompute for every sample
+        (by default only samples that generated <PAD> take it)."""
+        return engine.tf_beam_ids(self, enc_output, beam_width, max_length, sos, eos, return_scores=return_scores,
+                                  exact=exact)
 
     def beam_search_inference(self, enc_output, batch_size, vocabulary, beam_width, max_length):
         """Reference transformer.py:177-244: list of ``batch_size`` space-joined captions.  ``enc_output`` is

@@ -321,6 +321,15 @@ size_t capdec_tf_beam_workspace_bytes(const capdec_tf_model* m, int B, int W, in
 int capdec_tf_beam_search(const capdec_tf_model* m, const float* enc /*[B,S,E]*/, int B, int W, int S, int max_len,
                           int sos, int eos, int t_begin, int t_end, void* workspace, size_t workspace_bytes,
                           int64_t* out_ids, int32_t* out_len, float* out_scores, int32_t* n_unfinished, void* stream);
+/* KV-cached form of capdec_tf_beam_search: one new position per hypothesis and step, the key/value caches re-gathered
+ * after every selection.  pad_seen [B] (device) is set for samples in which some hypothesis received a <PAD> token:
+ * the reference lets a <PAD> query row attend uniformly over the CURRENT length (transformer.py:117-123), which no
+ * cache reproduces, so the caller redoes exactly those samples with capdec_tf_beam_search. */
+size_t capdec_tf_beam_cached_workspace_bytes(const capdec_tf_model* m, int B, int W, int S, int max_len);
+int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int B, int W, int S, int max_len, int sos,
+                                 int eos, int t_begin, int t_end, void* workspace, size_t workspace_bytes,
+                                 int64_t* out_ids, int32_t* out_len, float* out_scores, int32_t* n_unfinished,
+                                 int32_t* pad_seen, void* stream);
 size_t capdec_rnn_beam_workspace_bytes(const capdec_rnn_model* m, int B, int W, int max_len);
 /* x0 [B,E]: the BatchNorm'ed image projection (time-step 0 of the LSTM) */
 int capdec_rnn_beam_search(const capdec_rnn_model* m, const float* x0, int B, int W, int max_len, int sos, int eos,

@@ -36,11 +36,12 @@ def test_f11_transformer_beam_search(case):
             sd["fc2.bias"] = t(fx["b2__fc2.bias"])
         enc, want, ml = t(fx[case + "_enc"]), unpad(fx[case + "_ids"]), fx[case + "_ids"].shape[1]
     dec = decoder_from_sd(sd, H)
-    ids, lengths, scores = dec.beam_ids(enc.cuda(), R.SOS, R.EOS, W, ml, return_scores=True)
-    assert _rows(ids, lengths) == want
-    # the hypothesis scores (sums of log-probabilities, frozen once finished) against the oracle's
     _, _, want_scores = R.beam_search_ids(sd, enc, H, W, ml, return_state=True)
-    close(scores, want_scores, rtol=1e-4, atol=1e-5, what="scores")
+    for exact in (False, True):          # KV-cached (with the <PAD> samples redone) and full-prefix everywhere
+        ids, lengths, scores = dec.beam_ids(enc.cuda(), R.SOS, R.EOS, W, ml, return_scores=True, exact=exact)
+        assert _rows(ids, lengths) == want, exact
+        # the hypothesis scores (sums of log-probabilities, frozen once finished) against the oracle's
+        close(scores, want_scores, rtol=1e-4, atol=1e-5, what="scores")
 
 
 def test_f11_beam_api_strings_and_repeated_memory():
@@ -100,7 +101,25 @@ def test_beam_medium_size_against_oracle():
     sd = cpu_sd(dec)
     g = torch.Generator().manual_seed(77)
     enc = torch.randn(6, 2, 512, generator=g)
-    ids, lengths, scores = dec.beam_ids(enc.cuda(), R.SOS, R.EOS, 3, 10, return_scores=True)
     want, _, want_scores = R.beam_search_ids(sd, enc, 4, 3, 10, return_state=True)
-    close(scores, want_scores, rtol=1e-4, atol=1e-4, what="scores")
-    assert _rows(ids, lengths) == want
+    for exact in (False, True):
+        ids, lengths, scores = dec.beam_ids(enc.cuda(), R.SOS, R.EOS, 3, 10, return_scores=True, exact=exact)
+        close(scores, want_scores, rtol=1e-4, atol=1e-4, what="scores")
+        assert _rows(ids, lengths) == want
+
+
+def test_cached_beam_equals_full_prefix_beam_at_batch_256():
+    """Rows are independent and the two forms compute the same function: identical best hypotheses (up to a
+    near-tie) and scores on a larger batch with one and with 64 memory rows."""
+    from gpu_util import plain_decoder
+    torch.manual_seed(2)
+    dec = plain_decoder(512, 10000, 4, 2).cuda().eval()
+    g = torch.Generator().manual_seed(78)
+    for S in (1, 64):
+        enc = torch.randn(256, S, 512, generator=g).cuda()
+        a = dec.beam_ids(enc, R.SOS, R.EOS, 3, 20, return_scores=True)
+        b = dec.beam_ids(enc, R.SOS, R.EOS, 3, 20, return_scores=True, exact=True)
+        ra, rb = _rows(a[0], a[1]), _rows(b[0], b[1])
+        assert sum(x != y for x, y in zip(ra, rb)) <= 2
+        same = [i for i, (x, y) in enumerate(zip(ra, rb)) if x == y]
+        close(a[2][same], b[2][same], rtol=1e-4, atol=1e-4, what="scores")
