@@ -1,9 +1,12 @@
 // Fused LSTM step for gfx950: the gate contraction [B, E+Hd] x [E+Hd, 4Hd] on fp32 MFMA with the
 // gate non-linearities and the cell update in the epilogue (nn.LSTM gate order i,f,g,o).
 //
-// A wavefront owns 32 samples x 32 hidden units and keeps FOUR 32x32 accumulators, one per gate, with
-// identical (sample, unit) -> (register, lane) maps, so c' and h' are computed in registers and the
-// [B,4Hd] gate tensor is never written (unless the caller asks for it for a backward pass).
+// A workgroup owns 32 samples x 64 hidden units; its four wavefronts split that tile by unit half (32 units) and by
+// gate pair: two wavefronts accumulate the i and f gates, two the g and o gates, each with two 32x32 accumulators whose
+// (sample, unit) -> (register, lane) maps are identical.  (One wavefront with all four gates would leave half of the
+// chip's SIMDs idle at batch 1024: the MFMA pipe is per SIMD.)  After the k loop the g/o wavefronts pass their
+// accumulators through LDS to their i/f partners, which compute c' and h' in registers, so the [B,4Hd] gate tensor
+// is never written (unless the caller asks for it for a backward pass).
 // The k loop runs over two operand pairs back to back: (x, W_ih) then (h, W_hh).
 #include "common.h"
 #include <math.h>
@@ -12,7 +15,7 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDK = 36;
-constexpr int TB = 64;                 // samples per workgroup
+constexpr int TB = 32;                 // samples per workgroup
 constexpr int TU = 64;                 // hidden units per workgroup
 constexpr int LSTM_LDS_FLOATS = 2 * (TB + 4 * TU) * LDK;
 
@@ -49,16 +52,16 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     float* Ps = lds;                       // [2][TB][LDK]
     float* Qs = lds + 2 * TB * LDK;        // [2][4*TU][LDK], row = gate*TU + local unit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
+    const int wg = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;   // wg: gate pair (i,f) or (g,o)
     const int lrow = tid >> 3, lk = (tid & 7) * 4;
     const int i0 = blockIdx.y * TB, u0 = blockIdx.x * TU;
     const int nkx = (a.E + BK - 1) / BK;
     const int nkh = a.h0 ? (a.Hd + BK - 1) / BK : 0;
     const int nk = nkx + nkh;
 
-    f32x16 acc[4];
+    f32x16 acc[2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
 
@@ -96,18 +99,18 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) gload(kt + 1);
-        const float* pa = &Ps[(cur * TB + wi * 32 + r) * LDK + 4 * h];
-        const float* qa = &Qs[(cur * 4 * TU + wj * 32 + r) * LDK + 4 * h];
+        const float* pa = &Ps[(cur * TB + r) * LDK + 4 * h];
+        const float* qa = &Qs[(cur * 4 * TU + 2 * wg * TU + wj * 32 + r) * LDK + 4 * h];
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(pa + kc * 8);
-            f32x4 bv[4];
+            f32x4 bv[2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(qa + g * TU * LDK + kc * 8);
+            for (int g = 0; g < 2; ++g) bv[g] = *reinterpret_cast<const f32x4*>(qa + g * TU * LDK + kc * 8);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 2; ++g)
                     acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[g][m], acc[g], 0, 0, 0);
         }
         if (more) lstore(cur ^ 1);
@@ -115,6 +118,17 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
         cur ^= 1;
     }
 
+    // the loop ended on a barrier: the tile buffers are free.  g/o wavefronts hand their accumulators to the i/f
+    // wavefront of the same unit half: [wj][gate][register][lane]
+    float* xch = lds;
+    if (wg == 1) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xch[((wj * 2 + g) * 16 + e) * 64 + lane] = acc[g][e];
+    }
+    __syncthreads();
+    if (wg == 1) return;
     const int u = u0 + wj * 32 + r;
     if (u >= a.Hd) return;
     float bias[4];
@@ -122,10 +136,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     for (int g = 0; g < 4; ++g) bias[g] = a.b_ih[g * a.Hd + u] + a.b_hh[g * a.Hd + u];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int i = i0 + wi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (i >= a.B) continue;
         const float gi = acc[0][e] + bias[0], gf = acc[1][e] + bias[1];
-        const float gg = acc[2][e] + bias[2], go = acc[3][e] + bias[3];
+        const float gg = xch[((wj * 2 + 0) * 16 + e) * 64 + lane] + bias[2];
+        const float go = xch[((wj * 2 + 1) * 16 + e) * 64 + lane] + bias[3];
         const float cp = a.c0 ? a.c0[(int64_t)i * a.Hd + u] : 0.f;
         const float cn = sigmoidf_(gf) * cp + sigmoidf_(gi) * tanhf(gg);
         const float hn = sigmoidf_(go) * tanhf(cn);
