@@ -396,3 +396,27 @@ def test_gemm_split_k_atomic_and_forced_tiles(ops):
             close(ops.linear_dgrad(dy.cuda(), Wd.cuda()), dy.double() @ Wd.double(), what=f"dgrad cfg {cfg}")
     finally:
         lib.capdec_gemm_force_config(0)
+
+
+def test_maximum_length_50_forward_greedy_and_beam():
+    """The positional-encoding buffer holds 50 positions (transformer.py:58): teacher-forced logits at T=50, and greedy
+    and beam decodes of the full 50 steps (cached, exact, with PAD rows mid-sequence) against the oracle."""
+    fx = load_golden("f5_greedy")
+    sd = sub_sd(fx, "b__sd__")                      # the weight set that emits <PAD> often
+    H = int(fx["H"])
+    dec = decoder_from_sd(sd, H)
+    g = torch.Generator().manual_seed(50)
+    enc = torch.randn(4, 2, 64, generator=g)
+    ids = torch.randint(0, 50, (4, 50), generator=g)
+    ids[:, 0] = 1
+    with torch.no_grad():
+        close(dec.decoder_forward(enc.cuda(), ids.cuda()), R.decoder_forward(sd, enc, ids, H), what="logits T=50")
+    got, _ = _greedy(dec, enc, 50)
+    check_greedy(got, sd, enc, H, 50)
+    exact, _ = _greedy(dec, enc, 50, exact=True)
+    check_greedy(exact, sd, enc, H, 50)
+    from capdec.engine import ids_to_lists
+    want = R.beam_search_ids(sd, enc, H, 2, 50)
+    for ex in (False, True):
+        b_ids, b_len = dec.beam_ids(enc.cuda(), R.SOS, R.EOS, 2, 50, exact=ex)
+        assert ids_to_lists(b_ids, b_len) == want, ex
