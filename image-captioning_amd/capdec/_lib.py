@@ -79,7 +79,7 @@ _SIGNATURES = {
     "capdec_gemm_ex": (c_int, [POINTER(GemmGroup), c_int, c_int, c_int, POINTER(GemmExtra), _P]),
     "capdec_dropout": (c_int, [_P, c_int64, c_float, c_uint64, _P, _P]),
     "capdec_add_layernorm_train": (c_int, [_P, c_int, _P, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
-    "capdec_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
+    "capdec_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P, _P]),
     "capdec_colsum": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
     "capdec_softmax_nll_grad": (c_int, [_P, c_int64, _P, c_int, c_int, c_int64, _P, _P, _P, _P]),
     "capdec_group_sum": (c_int, [_P, c_int, c_int, c_int, _P, _P]),

@@ -31,10 +31,11 @@ def _new(grads, name, like):
     return g
 
 
-def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None):
-    """Backward of y = x W^T + b: fills grads[prefix.weight/.bias]; returns dX (added onto ``accum`` if given)."""
+def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None, bias_done=False):
+    """Backward of y = x W^T + b: fills grads[prefix.weight/.bias]; returns dX (added onto ``accum`` if given).
+    bias_done: the bias gradient was already accumulated by the kernel that produced dy."""
     ops.linear_wgrad(dy, x, out=_new(grads, prefix + ".weight", lin.weight))
-    if lin.bias is not None:
+    if lin.bias is not None and not bias_done:
         ops.colsum(dy, _new(grads, prefix + ".bias", lin.bias))
     if need_dx:
         return ops.linear_dgrad(dy, lin.weight, mask=mask, accum=accum)
@@ -111,24 +112,28 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         sd = t.seed + (3 * l + 1) * _SITE
         sa, ca, ff = ly.self_attn, ly.cross_attn, ly.feed_forward
         # x3 = LN3(x2 + drop(f)),  f = relu(x2 W1^T + b1) W2^T + b2
+        # (the bias gradient of the layer in front of each LayerNorm is the column sum of that LayerNorm's d_x: the
+        #  LayerNorm backward kernel accumulates it next to dgamma / dbeta)
         d_x2, d_f = ops.layernorm_bwd(dx, c.s3, c.m3, c.r3, ly.norm3.weight, p, sd + 2 * _SITE,
                                       _new(grads, pre + "norm3.weight", ly.norm3.weight),
-                                      _new(grads, pre + "norm3.bias", ly.norm3.bias))
-        dh = _lin_bwd(grads, pre + "feed_forward.fc2", ff.fc2, d_f, c.h, mask=c.h)       # ReLU backward fused
+                                      _new(grads, pre + "norm3.bias", ly.norm3.bias),
+                                      dxsum=_new(grads, pre + "feed_forward.fc2.bias", ff.fc2.bias))
+        dh = _lin_bwd(grads, pre + "feed_forward.fc2", ff.fc2, d_f, c.h, mask=c.h, bias_done=True)   # ReLU backward fused
         _lin_bwd(grads, pre + "feed_forward.fc1", ff.fc1, dh, c.x2, accum=d_x2)
         # x2 = LN2(x1 + drop(a2)),  a2 = attn(x1 Wq, enc Wk, enc Wv) Wo
         d_x1, d_a2 = ops.layernorm_bwd(d_x2, c.s2, c.m2, c.r2, ly.norm2.weight, p, sd + _SITE,
                                        _new(grads, pre + "norm2.weight", ly.norm2.weight),
-                                       _new(grads, pre + "norm2.bias", ly.norm2.bias))
+                                       _new(grads, pre + "norm2.bias", ly.norm2.bias),
+                                       dxsum=_new(grads, pre + "cross_attn.W_o.bias", ca.W_o.bias))
         if t.shortcut:
             d_cc = ops.group_sum(d_a2, T)                                              # [B,E]
-            d_v2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_cc, c.v2)
+            d_v2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_cc, c.v2, bias_done=True)
             _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, d_v2, t.enc, need_dx=need_denc, accum=denc)
             for n, prm in (("W_q.weight", ca.W_q.weight), ("W_q.bias", ca.W_q.bias), ("W_k.weight", ca.W_k.weight),
                            ("W_k.bias", ca.W_k.bias)):
                 _new(grads, pre + "cross_attn." + n, prm)                              # exactly zero
         else:
-            d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2)
+            d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2, bias_done=True)
             dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S, out=c.ao2)
             _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1)
             _lin_bwd(grads, pre + "cross_attn.W_k", ca.W_k, dk2, t.enc, need_dx=need_denc, accum=denc)
@@ -136,8 +141,9 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         # x1 = LN1(x + drop(a)),  a = attn(x Wq, x Wk, x Wv; causal, PAD rows) Wo
         d_x, d_a = ops.layernorm_bwd(d_x1, c.s1, c.m1, c.r1, ly.norm1.weight, p, sd,
                                      _new(grads, pre + "norm1.weight", ly.norm1.weight),
-                                     _new(grads, pre + "norm1.bias", ly.norm1.bias))
-        d_ao = _lin_bwd(grads, pre + "self_attn.W_o", sa.W_o, d_a, c.ao)
+                                     _new(grads, pre + "norm1.bias", ly.norm1.bias),
+                                     dxsum=_new(grads, pre + "self_attn.W_o.bias", sa.W_o.bias))
+        d_ao = _lin_bwd(grads, pre + "self_attn.W_o", sa.W_o, d_a, c.ao, bias_done=True)
         dq, dk, dv = ops.attention_bwd(c.qkv[0], c.qkv[1], c.qkv[2], d_ao, c.lse, B, H, T, T, causal=True,
                                        ids32=t.ids32)
         _lin_bwd(grads, pre + "self_attn.W_q", sa.W_q, dq, c.x, accum=d_x)

@@ -362,8 +362,9 @@ def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5, x_div=1):
     return y, s, mean, rstd
 
 
-def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta):
-    """Returns (d_add, d_x); dgamma/dbeta are accumulated."""
+def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None):
+    """Returns (d_add, d_x); dgamma/dbeta are accumulated, and so are the column sums of d_x into ``dxsum`` [E]
+    when given (the bias gradient of the linear layer whose output was normalised)."""
     lib = _lib.load()
     M, E = dy.shape
     if not dy.is_contiguous():
@@ -372,7 +373,7 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta):
     d_x = torch.empty_like(d_add) if p > 0 else None
     _lib.check(lib.capdec_layernorm_bwd(_chk(dy).data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                         _chk(gamma).data_ptr(), M, E, p, seed, d_add.data_ptr(), _ptr(d_x),
-                                        _chk(dgamma).data_ptr(), _chk(dbeta).data_ptr(), _stream()),
+                                        _chk(dgamma).data_ptr(), _chk(dbeta).data_ptr(), _ptr(dxsum), _stream()),
                "capdec_layernorm_bwd")
     return d_add, (d_x if p > 0 else d_add)
 

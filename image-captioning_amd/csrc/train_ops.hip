@@ -138,19 +138,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int M, int E, float p,
                                                      uint64_t seed, float* __restrict__ d_add, float* __restrict__ d_x,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][2][E]
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dxsum) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][3][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nv = E / 4;
     const float inv_keep = 1.0f / (1.0f - p);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
-    f32x4 gam[NV], ag[NV], ab[NV];
+    f32x4 gam[NV], ag[NV], ab[NV], ax[NV];     // ax: column sums of d_x (the bias gradient of the layer that made x)
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
         gam[u] = c < nv ? g4[c] : f32x4{0.f, 0.f, 0.f, 0.f};
         ag[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         ab[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ax[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int r0 = blockIdx.x * LNB_ROWS;
     for (int rr = wave; rr < LNB_ROWS; rr += 4) {
@@ -184,36 +186,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             if (c < nv) {
                 f32x4 ds = (g[u] - c1 - xh[u] * c2) * rs;
                 if (d_add) reinterpret_cast<f32x4*>(d_add + (int64_t)row * E)[c] = ds;
-                if (d_x) {
+                if (d_x || dxsum) {
                     if (p > 0.f) {
                         ds *= drop_scale4(seed, (uint64_t)row * E + 4 * c, p, inv_keep);
                     }
-                    reinterpret_cast<f32x4*>(d_x + (int64_t)row * E)[c] = ds;
+                    if (d_x) reinterpret_cast<f32x4*>(d_x + (int64_t)row * E)[c] = ds;
+                    ax[u] += ds;
                 }
             }
         }
     }
     // combine the 4 wavefronts' column partials, then one atomic per column and workgroup
-    float* pg = lds + (wave * 2 + 0) * E;
-    float* pb = lds + (wave * 2 + 1) * E;
+    float* pg = lds + (wave * 3 + 0) * E;
+    float* pb = lds + (wave * 3 + 1) * E;
+    float* px = lds + (wave * 3 + 2) * E;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int c = lane + 64 * u;
         if (c < nv) {
             reinterpret_cast<f32x4*>(pg)[c] = ag[u];
             reinterpret_cast<f32x4*>(pb)[c] = ab[u];
+            reinterpret_cast<f32x4*>(px)[c] = ax[u];
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < E; c += 256) {
-        float sg = 0.f, sb = 0.f;
+        float sg = 0.f, sb = 0.f, sx = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            sg += lds[(w * 2 + 0) * E + c];
-            sb += lds[(w * 2 + 1) * E + c];
+            sg += lds[(w * 3 + 0) * E + c];
+            sb += lds[(w * 3 + 1) * E + c];
+            sx += lds[(w * 3 + 2) * E + c];
         }
         atomicAdd(&dgamma[c], sg);
         atomicAdd(&dbeta[c], sb);
+        if (dxsum) atomicAdd(&dxsum[c], sx);
     }
 }
 
@@ -907,16 +914,20 @@ int capdec_add_layernorm_train(const float* x, int x_div, const float* add, cons
 
 int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                          int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma, float* dbeta,
-                         void* stream) {
+                         float* dxsum, void* stream) {
     CAPDEC_REQUIRE(dy && s && mean && rstd && gamma && dgamma && dbeta && M >= 0 && E >= 4 && E % 4 == 0 &&
                    E <= 256 * LN_MAXV && p >= 0.f && p < 1.f);
     if (!capdec_aligned16(dy) || !capdec_aligned16(s) || !capdec_aligned16(gamma) || (d_add && !capdec_aligned16(d_add)) ||
         (d_x && !capdec_aligned16(d_x)))
         return CAPDEC_EALIGN;
     if (M == 0) return 0;
+    // rows wider than 1365 floats need more than the default 64 KiB of dynamic LDS (only the widest instantiation)
+    static const bool wide_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<8>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 2048 * 4) == hipSuccess;
+    if (!wide_ok) return CAPDEC_EINVAL;
 #define CAPDEC_CALL(NV_)                                                                                           \
-    hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 8 * E * sizeof(float),     \
-                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, d_add, d_x, dgamma, dbeta)
+    hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 12 * E * sizeof(float),    \
+                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, d_add, d_x, dgamma, dbeta, dxsum)
     CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();

@@ -163,10 +163,11 @@ int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, 
 int capdec_add_layernorm_train(const float* x, int x_div, const float* add, const float* gamma, const float* beta,
                                float eps, int M, int E, float p, uint64_t seed, float* y, float* s_out, float* mean,
                                float* rstd, void* stream);
-/* d_add = dLN/ds ; d_x = d_add * dropout mask (same p, seed as the forward) ; dgamma/dbeta accumulated */
+/* d_add = dLN/ds ; d_x = d_add * dropout mask (same p, seed as the forward) ; dgamma/dbeta accumulated;
+ * dxsum (nullable, [E], accumulated): column sums of d_x = the bias gradient of the linear layer that produced x */
 int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                          int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma, float* dbeta,
-                         void* stream);
+                         float* dxsum, void* stream);
 /* out[j] += sum_i x[i*ldx + j] */
 int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream);
 /* out[g,:] = sum over t < T of x[g*T + t, :]  (gradient of a row that was broadcast over T positions) */
