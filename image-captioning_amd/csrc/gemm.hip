@@ -292,10 +292,200 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ P, const floa
     }
 }
 
+// ---- the same contraction with the operand tiles written to LDS by the load itself ------------------------------
+// For operands made of whole k-tiles of 16-byte aligned vectors (VEC, K % BK == 0).  Each global_load_lds_dwordx4
+// writes one *piece* -- 1 KiB of LDS, lane l at byte 16*l, whatever address the lane loads from -- so the LDS image
+// of a tile is linear and unpadded:
+//   k-contiguous operand   [row][BK]: a piece is 256/BK rows.  Bank conflicts of the 16-byte fragment reads are
+//                          avoided by an XOR swizzle of a row's 16-byte slots (slot = chunk ^ swz(row)), applied to
+//                          the per-lane SOURCE address when a piece is loaded and to the LDS address when a fragment
+//                          is read.
+//   row-contiguous operand [k][NX]:   a piece is 256/NX k-rows; the four 4-byte fragment reads of a half-wave hit 32
+//                          consecutive floats, conflict-free as they are.
+// No staging registers and no ds_write: two or three LDS buffers of (BI+BJ)*BK floats per k-group, one barrier per k-tile, the
+// load of a group's next tile issued part-way through the current tile's multiply.
+template <int BK>
+__device__ __forceinline__ int dma_swz(int row) {
+    // 16-byte slots per 256-byte bank row: 16.  BK = 16: a row is 4 slots, the rows of one 16-lane read group that
+    // share row % 4 have (row / 4) % 8 in {0,3,5,6} or {1,2,4,7}, which this maps to four distinct values.
+    // BK = 32: a row is 8 slots and the rows of a group that share row % 2 have distinct (row / 2) % 8.
+    if (BK == 16) {
+        const int q = (row >> 2) & 7;
+        return (q & 3) ^ ((q >> 2) * 3);
+    }
+    return (row >> 1) & 7;
+}
+
+template <int NX_, int BK, bool T>
+struct DmaOperand {
+    static constexpr int NX = NX_;
+    static constexpr int PIECES = NX * BK / 256;
+    static constexpr int SLOTS = BK / 4, PR = 64 / SLOTS;     // k-contiguous: 16-byte slots per row, rows per piece
+    static constexpr int CPR = NX / 4, KPP = 64 / CPR;        // row-contiguous: vectors per k-row, k-rows per piece
+    static_assert(PIECES >= 1 && (T ? (CPR <= 64 && BK % KPP == 0) : (NX % PR == 0)), "tile does not cut into pieces");
+    // where this lane reads from for piece `pl` of k-tile `kt`
+    __device__ static const float* source(const float* base, int64_t ld, int n, int x0, int kt, int pl, int lane) {
+        if (!T) {
+            const int row = pl * PR + lane / SLOTS;
+            const int chunk = (lane % SLOTS) ^ dma_swz<BK>(row);
+            return base + (int64_t)min(x0 + row, n - 1) * ld + (int64_t)kt * BK + chunk * 4;
+        }
+        const int kr = pl * KPP + lane / CPR, chunk = lane % CPR;
+        return base + ((int64_t)kt * BK + kr) * ld + min(x0 + 4 * chunk, n - 4);
+    }
+    __device__ static int64_t step(int64_t ld) { return T ? (int64_t)BK * ld : (int64_t)BK; }
+    // the four k values {kc*8 + 4h + m} of row (w0 + r) for the lane (r, h)
+    __device__ static f32x4 frag(const float* img, int w0, int kc, int r, int h) {
+        if (!T) return *reinterpret_cast<const f32x4*>(img + (w0 + r) * BK + (((kc * 2 + h) ^ dma_swz<BK>(w0 + r)) * 4));
+        const float* q = img + (kc * 8 + 4 * h) * NX + w0 + r;
+        return f32x4{q[0], q[NX], q[2 * NX], q[3 * NX]};
+    }
+};
+
+// k-groups > 1 mark the tiles picked for launches too small to fill the chip: those get the deeper ring and issue
+// their loads first
+template <int KG>
+constexpr int dma_nbuf() { return KG > 1 ? 3 : 2; }
+template <int BK, int KG>
+constexpr int dma_cut() { return KG > 1 ? 0 : BK / 16; }
+
+template <int WM, int WI, int WJ, int BK, int KG>
+constexpr int dma_lds_floats() { return KG * dma_nbuf<KG>() * (32 * WM * WI + 64 * WJ) * BK; }
+
+template <int WM, int WI, int WJ, int BK, int CUT, int NBUF = 2, bool TP = false, bool TQ = false, int KG = 1>
+__device__ __forceinline__ void mainloop_dma(const float* __restrict__ P, const float* __restrict__ Q, int64_t ldp,
+                                             int64_t ldq, int I, int J, int i0, int j0, int kt0, int kt1, float* lds,
+                                             f32x16 (&acc)[WI][WJ]) {
+    static_assert(BK == 16 || BK == 32, "k-tile depths built: 16 and 32");
+    constexpr int GT = 128 * WM, WAVES = 2 * WM;
+    constexpr int BI = 32 * WM * WI, BJ = 64 * WJ;
+    using OpP = DmaOperand<BI, BK, TP>;
+    using OpQ = DmaOperand<BJ, BK, TQ>;
+    constexpr int NP = OpP::PIECES + OpQ::PIECES, NPW = NP / WAVES;
+    constexpr int BUF = (BI + BJ) * BK, QOFF = BI * BK;
+    static_assert(NP % WAVES == 0, "pieces do not divide over the wavefronts");
+    const int kg = KG > 1 ? (int)(threadIdx.x / GT) : 0;
+    const int tid = threadIdx.x % GT;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = WM == 2 ? wave >> 1 : 0, wj = wave & 1, r = lane & 31, h = lane >> 5;
+    float* glds = lds + kg * NBUF * BUF;
+#pragma unroll
+    for (int ti = 0; ti < WI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < WJ; ++tj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ti][tj][e] = 0.f;
+    if (kt0 >= kt1) return;
+
+    // this lane's source address inside each of its wavefront's pieces; a k-group walks the tiles kt0+kg, kt0+kg+KG, ...
+    const float* src[NPW];
+    int dst[NPW];
+    int64_t stp[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int piece = i * WAVES + wave;                       // wave-uniform
+        if (piece < OpP::PIECES) {
+            src[i] = OpP::source(P, ldp, I, i0, kt0 + kg, piece, lane);
+            dst[i] = piece * 256;
+            stp[i] = OpP::step(ldp) * KG;
+        } else {
+            src[i] = OpQ::source(Q, ldq, J, j0, kt0 + kg, piece - OpP::PIECES, lane);
+            dst[i] = QOFF + (piece - OpP::PIECES) * 256;
+            stp[i] = OpQ::step(ldq) * KG;
+        }
+    }
+    auto issue = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                             (__attribute__((address_space(3))) void*)(glds + buf * BUF + dst[i]), 16, 0, 0);
+            src[i] += stp[i];
+        }
+    };
+    auto compute = [&](int buf, int kc_lo, int kc_hi) {
+        const float* b0 = glds + buf * BUF;
+#pragma unroll
+        for (int kc = kc_lo; kc < kc_hi; ++kc) {
+            f32x4 a[WI], b[WJ];
+#pragma unroll
+            for (int ti = 0; ti < WI; ++ti) a[ti] = OpP::frag(b0, wi * 32 * WI + ti * 32, kc, r, h);
+#pragma unroll
+            for (int tj = 0; tj < WJ; ++tj) b[tj] = OpQ::frag(b0 + QOFF, wj * 32 * WJ + tj * 32, kc, r, h);
+            // lane half h feeds k = kc*8 + 4h + m, so MFMA m sums k in {kc*8+m, kc*8+4+m}
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int ti = 0; ti < WI; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < WJ; ++tj)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][m], b[tj][m], acc[ti][tj], 0, 0, 0);
+        }
+    };
+    const int nit = (kt1 - kt0 + KG - 1) / KG;    // the same trip count in every k-group (shared barriers)
+    auto live = [&](int it) { return KG == 1 ? it < nit : kt0 + kg + it * KG < kt1; };
+    // CUT = the k-chunks (of 8) multiplied before the loads of a later tile are issued.  Issuing them first costs the
+    // wavefront's own MFMA stream the most (the loads and the first fragment reads queue together); issuing them
+    // last exposes their whole latency to this wavefront, which only pays when enough other wavefronts share the SIMD.
+    // NBUF = LDS buffers per k-group: NBUF - 1 tiles are in flight or being read at any time.  Three buffers let a
+    // workgroup that is alone on its CU keep two tiles' worth of loads outstanding across each barrier.
+    constexpr int NKC = BK / 8;
+    static_assert(CUT >= 0 && CUT <= NKC && (NBUF == 2 || NBUF == 3), "load issue point / ring depth not built");
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j)
+        if (live(j)) issue(j);
+    for (int it0 = 0; it0 < nit; it0 += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            const int it = it0 + j;
+            if (it >= nit) break;
+            // Every piece of tile `it` has landed (the loads of a later tile may stay in flight: they retire in
+            // order) and every wavefront is done reading the buffer that the next loads overwrite.
+            if (NBUF == 3 && live(it + 1)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (CUT > 0 && live(it)) compute(j, 0, CUT);
+            __builtin_amdgcn_sched_barrier(0);
+            if (live(it + NBUF - 1)) issue((j + NBUF - 1) % NBUF);
+            __builtin_amdgcn_sched_barrier(0);
+            if (CUT < NKC && live(it)) compute(j, CUT, NKC);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();   // past here the caller (or the k-group sum below) may reuse `lds`
+    if (KG > 1) {
+        // sum the k-groups' partial tiles into group 0: [group-1][wave][register][lane] floats
+        float* red = lds;
+        constexpr int PER_WAVE = WI * WJ * 16 * 64;
+        if (kg > 0) {
+            float* d = red + ((kg - 1) * 2 * WM + wave) * PER_WAVE + lane;
+#pragma unroll
+            for (int ti = 0; ti < WI; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < WJ; ++tj)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) d[((ti * WJ + tj) * 16 + e) * 64] = acc[ti][tj][e];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int g = 1; g < KG; ++g) {
+                const float* sp = red + ((g - 1) * 2 * WM + wave) * PER_WAVE + lane;
+#pragma unroll
+                for (int ti = 0; ti < WI; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < WJ; ++tj)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[ti][tj][e] += sp[((ti * WJ + tj) * 16 + e) * 64];
+            }
+        }
+    }
+}
+
 // accumulator register e of lane-half h is row (e&3) + 8*(e>>2) + 4*h of the 32x32 tile
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
-template <int WM, int WI, int WJ, int BK, bool VEC, bool TP, bool TQ, int KG>
+template <int WM, int WI, int WJ, int BK, bool VEC, bool TP, bool TQ, int KG, bool DMA = false>
 __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3 : 1) void gemm_kernel(GemmKArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int z, tile_i, tile_j;
@@ -311,7 +501,8 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
     const int per = (nk + args.nsplit - 1) / args.nsplit;
     const int kt0 = split * per, kt1 = min(nk, kt0 + per);
     f32x16 acc[WI][WJ];
-    mainloop<WM, WI, WJ, BK, VEC, TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, nI, g.J, args.K, i0, j0, kt0, kt1, lds, acc);
+    if (DMA) mainloop_dma<WM, WI, WJ, BK, dma_cut<BK, KG>(), dma_nbuf<KG>(), TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, nI, g.J, i0, j0, kt0, kt1, lds, acc);
+    else mainloop<WM, WI, WJ, BK, VEC, TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, nI, g.J, args.K, i0, j0, kt0, kt1, lds, acc);
     if (KG > 1 && threadIdx.x >= 128 * WM) return;   // group 0 holds the summed tile
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -365,7 +556,7 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
 
 // ---- vocabulary projection with lane-local reductions over the vocabulary axis -------------------
 // P = W [V,K] (i = vocabulary id), Q = x [M,K] (j = row).  MODE 0: arg-max; MODE 1: (max, sum exp).
-template <int WI, int WJ, int BK, bool VEC, int MODE>
+template <int WI, int WJ, int BK, bool VEC, int MODE, bool DMA = false>
 __global__ __launch_bounds__(256, 5) void vocab_reduce_kernel(const float* __restrict__ W, const float* __restrict__ x,
                                                            int64_t ldx, const float* __restrict__ bias, int V, int M,
                                                            int K, float* __restrict__ out_a, void* __restrict__ out_b,
@@ -376,7 +567,8 @@ __global__ __launch_bounds__(256, 5) void vocab_reduce_kernel(const float* __res
     if (!tile_of_block(map, blockIdx.x, z, tile_i, tile_j)) return;
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
     f32x16 acc[WI][WJ];
-    mainloop<2, WI, WJ, BK, VEC>(W, x, (int64_t)K, ldx, V, M, K, i0, j0, 0, (K + BK - 1) / BK, lds, acc);
+    if (DMA) mainloop_dma<2, WI, WJ, BK, BK / 8>(W, x, (int64_t)K, ldx, V, M, i0, j0, 0, K / BK, lds, acc);
+    else mainloop<2, WI, WJ, BK, VEC>(W, x, (int64_t)K, ldx, V, M, K, i0, j0, 0, (K + BK - 1) / BK, lds, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
@@ -531,6 +723,9 @@ __global__ __launch_bounds__(256) void nll_finalize_kernel(const float* __restri
     }
 }
 
+// 0: automatic; 1: operand tiles always staged through registers
+int g_staging = 0;
+
 // workgroups above 64 KiB of dynamic LDS need the limit raised once per kernel
 template <typename F>
 bool allow_lds(F* kernel, size_t bytes) {
@@ -558,6 +753,15 @@ int launch_gemm_cfg(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hip
     static const bool ready = allow_lds(gemm_kernel<WM, WI, WJ, BK, true, TP, TQ, KG>, smem) &&
                               allow_lds(gemm_kernel<WM, WI, WJ, BK, false, TP, TQ, KG>, smem);
     if (!ready) return CAPDEC_EINVAL;
+    if (vec && a.K % BK == 0 && g_staging != 1) {
+        // whole k-tiles of aligned vectors: loaded straight into LDS
+        constexpr size_t smem_dma = dma_lds_floats<WM, WI, WJ, BK, KG>() * sizeof(float);
+        static const bool ready_dma = allow_lds(gemm_kernel<WM, WI, WJ, BK, true, TP, TQ, KG, true>, smem_dma);
+        if (!ready_dma) return CAPDEC_EINVAL;
+        hipLaunchKernelGGL((gemm_kernel<WM, WI, WJ, BK, true, TP, TQ, KG, true>), grid, dim3(NT), smem_dma, s, a);
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
     if (vec) hipLaunchKernelGGL((gemm_kernel<WM, WI, WJ, BK, true, TP, TQ, KG>), grid, dim3(NT), smem, s, a);
     else hipLaunchKernelGGL((gemm_kernel<WM, WI, WJ, BK, false, TP, TQ, KG>), grid, dim3(NT), smem, s, a);
     CAPDEC_LAUNCH_CHECK();
@@ -639,6 +843,12 @@ int capdec_gemm_force_config(int cfg) {
     return 0;
 }
 
+int capdec_gemm_force_staging(int mode) {
+    CAPDEC_REQUIRE(mode == 0 || mode == 1);
+    g_staging = mode;
+    return 0;
+}
+
 int capdec_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, void* stream) {
     return capdec_launch_gemm(groups, ngroups, K, flags, (hipStream_t)stream, nullptr);
 }
@@ -661,13 +871,22 @@ static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const floa
     constexpr int VBK = 16;   // 64x128 tile at BK 16: 30 KiB of LDS, five workgroups per CU (1256 tiles at V=10000, M=1024: 4.9 per CU)
     constexpr size_t smem_w = lds_floats<2, VOCAB_WI, 2, VBK, false, false, 1>() * sizeof(float);
     constexpr size_t smem_n = lds_floats<2, VOCAB_WI, 1, VBK, false, false, 1>() * sizeof(float);
-    const size_t smem = wide ? smem_w : smem_n;
+    // operand tiles go to LDS straight from the load when every 16-float k-tile is whole and 16-byte aligned
+    const bool dma = vec && K % VBK == 0 && g_staging != 1;
+    const size_t smem = dma ? (wide ? dma_lds_floats<2, VOCAB_WI, 2, VBK, 1>() : dma_lds_floats<2, VOCAB_WI, 1, VBK, 1>()) * sizeof(float)
+                            : (wide ? smem_w : smem_n);
     TileMap map;
     dim3 grid(make_tile_map(map, nt, wide ? (M + 127) / 128 : (M + 63) / 64, 1, false), 1, 1);
 #define CAPDEC_VR(WJ_, VEC_, MODE_)                                                                                    \
     hipLaunchKernelGGL((vocab_reduce_kernel<VOCAB_WI, WJ_, VBK, VEC_, MODE_>), grid, dim3(256), smem, s, W, x, ldx, bias, V, \
                        M, K, out_a, out_b, nt, map)
-    if (mode == 0) {
+#define CAPDEC_VD(WJ_, MODE_)                                                                                          \
+    hipLaunchKernelGGL((vocab_reduce_kernel<VOCAB_WI, WJ_, VBK, true, MODE_, true>), grid, dim3(256), smem, s, W, x, ldx, bias, \
+                       V, M, K, out_a, out_b, nt, map)
+    if (dma) {
+        if (mode == 0) { if (wide) CAPDEC_VD(2, 0); else CAPDEC_VD(1, 0); }
+        else           { if (wide) CAPDEC_VD(2, 1); else CAPDEC_VD(1, 1); }
+    } else if (mode == 0) {
         if (wide) { if (vec) CAPDEC_VR(2, true, 0); else CAPDEC_VR(2, false, 0); }
         else      { if (vec) CAPDEC_VR(1, true, 0); else CAPDEC_VR(1, false, 0); }
     } else {
@@ -675,6 +894,7 @@ static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const floa
         else      { if (vec) CAPDEC_VR(1, true, 1); else CAPDEC_VR(1, false, 1); }
     }
 #undef CAPDEC_VR
+#undef CAPDEC_VD
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

@@ -398,6 +398,36 @@ def test_gemm_split_k_atomic_and_forced_tiles(ops):
         lib.capdec_gemm_force_config(0)
 
 
+def test_gemm_tiles_loaded_straight_into_lds(ops):
+    """Shapes made of whole, aligned k-tiles take the path whose loads write LDS directly: every tile configuration and
+    operand layout against fp64, and bit for bit against the register-staged path (same order of sums)."""
+    from capdec import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(78)
+    x, W, b = torch.randn(200, 1056, generator=g), torch.randn(136, 1056, generator=g), torch.randn(136, generator=g)
+    dy, xx = torch.randn(352, 72, generator=g), torch.randn(352, 132, generator=g)
+    dy2, Wd = torch.randn(300, 96, generator=g), torch.randn(96, 132, generator=g)
+    try:
+        for cfg in (0, 11, 116, 32, 22, 216):
+            lib.capdec_gemm_force_config(cfg)
+            outs = []
+            for staging in (1, 0):
+                lib.capdec_gemm_force_staging(staging)
+                y = ops.linear(x.cuda(), W.cuda(), b.cuda(), relu=True)
+                close(y, torch.relu(x.double() @ W.double().t() + b.double()), what=f"plain cfg {cfg} staging {staging}")
+                ys = ops.linear(x.cuda(), W.cuda(), b.cuda(), split_k=True)
+                close(ys, x.double() @ W.double().t() + b.double(), what=f"split-k cfg {cfg} staging {staging}")
+                dw = ops.linear_wgrad(dy.cuda(), xx.cuda())
+                close(dw, dy.double().t() @ xx.double(), what=f"wgrad cfg {cfg} staging {staging}")
+                dx = ops.linear_dgrad(dy2.cuda(), Wd.cuda())
+                close(dx, dy2.double() @ Wd.double(), what=f"dgrad cfg {cfg} staging {staging}")
+                outs.append((y, dx))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), f"cfg {cfg}"
+    finally:
+        lib.capdec_gemm_force_config(0)
+        lib.capdec_gemm_force_staging(0)
+
+
 def test_maximum_length_50_forward_greedy_and_beam():
     """The positional-encoding buffer holds 50 positions (transformer.py:58): teacher-forced logits at T=50, and greedy
     and beam decodes of the full 50 steps (cached, exact, with PAD rows mid-sequence) against the oracle."""
