@@ -77,6 +77,7 @@ _SIGNATURES = {
     "capdec_lstm_step_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, _P, _P, _P]),
     "capdec_gemm_force_config": (c_int, [c_int]),
     "capdec_gemm_force_staging": (c_int, [c_int]),
+    "capdec_lstm_force_staging": (c_int, [c_int]),
     "capdec_gemm_ex": (c_int, [POINTER(GemmGroup), c_int, c_int, c_int, POINTER(GemmExtra), _P]),
     "capdec_dropout": (c_int, [_P, c_int64, c_float, c_uint64, _P, _P]),
     "capdec_add_layernorm_train": (c_int, [_P, c_int, _P, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),

@@ -153,6 +153,139 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     }
 }
 
+// The same step with the operand tiles written to LDS by the loads themselves (global_load_lds_dwordx4: one 1 KiB
+// piece = 8 rows of 32 floats per wavefront instruction, lane l at byte 16*l).  For E and Hd multiples of 32 and
+// 16-byte aligned operands.  The tile image is linear, [288 rows][32 floats] (32 sample rows, then gate*64 + unit),
+// with the eight 16-byte slots of a row XOR-swizzled by (row/2)%8 -- applied to the source address of a piece and to
+// the LDS address of a fragment read -- so the fragment reads are bank-conflict free without padding.  Three
+// buffers: a workgroup is alone on its CU here, so two tiles' loads stay in flight across each barrier.  The sums
+// run in the same order as in the register-staged kernel.
+constexpr int DROWS = TB + 4 * TU;                 // rows of one tile image
+constexpr int DBUF = DROWS * BK;                   // floats per buffer
+constexpr int DNPW = DROWS / 8 / 4;                // pieces per wavefront and tile
+constexpr int DNBUF = 3;
+constexpr int LSTM_DMA_LDS_FLOATS = DNBUF * DBUF;
+static_assert(DROWS % 32 == 0 && 2 * DNPW <= 63, "tile does not cut into pieces");
+
+__device__ __forceinline__ int lstm_swz(int row) { return (row >> 1) & 7; }
+
+__global__ __launch_bounds__(256) void lstm_step_dma_kernel(LstmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;   // wg: gate pair (i,f) or (g,o)
+    const int i0 = blockIdx.y * TB, u0 = blockIdx.x * TU;
+    const int nkx = a.E / BK;
+    const int nkh = a.h0 ? a.Hd / BK : 0;
+    const int nk = nkx + nkh;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+
+    // this lane's source inside each of its wavefront's pieces, for the (x, W_ih) and the (h, W_hh) part of the k loop
+    const float* sx[DNPW];
+    const float* sh[DNPW];
+#pragma unroll
+    for (int i = 0; i < DNPW; ++i) {
+        const int piece = i * 4 + wave;                 // wave-uniform
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ lstm_swz(row);
+        if (piece * 8 < TB) {
+            const int smp = min(i0 + row, a.B - 1);
+            sx[i] = a.x + (int64_t)smp * a.ldx + chunk * 4;
+            sh[i] = a.h0 ? a.h0 + (int64_t)smp * a.ldh0 + chunk * 4 : a.x;
+        } else {
+            const int q = row - TB, g = q / TU, u = min(u0 + q % TU, a.Hd - 1);
+            sx[i] = a.w_ih + ((int64_t)g * a.Hd + u) * a.E + chunk * 4;
+            sh[i] = a.w_hh + ((int64_t)g * a.Hd + u) * a.Hd + chunk * 4;
+        }
+    }
+    auto issue = [&](int kt, int buf) {
+        const bool second = kt >= nkx;                  // uniform
+        const int off = (second ? kt - nkx : kt) * BK;
+#pragma unroll
+        for (int i = 0; i < DNPW; ++i) {
+            const float* src = (second ? sh[i] : sx[i]) + off;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + buf * DBUF + (i * 4 + wave) * 256),
+                                             16, 0, 0);
+        }
+    };
+    const int rq = TB + 2 * wg * TU + wj * 32 + r;
+    const int sp = lstm_swz(r), sq = lstm_swz(rq);
+    auto compute = [&](int buf) {
+        const float* b0 = lds + buf * DBUF;
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(b0 + r * BK + (((kc * 2 + h) ^ sp) * 4));
+            f32x4 bv[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                bv[g] = *reinterpret_cast<const f32x4*>(b0 + (rq + g * TU) * BK + (((kc * 2 + h) ^ sq) * 4));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[g][m], acc[g], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < DNBUF - 1; ++j)
+        if (j < nk) issue(j, j);
+    for (int kt0 = 0; kt0 < nk; kt0 += DNBUF) {
+#pragma unroll
+        for (int j = 0; j < DNBUF; ++j) {
+            const int kt = kt0 + j;
+            if (kt >= nk) break;
+            // tile kt has landed (the loads of tile kt+1 may stay in flight: they retire in order) and every
+            // wavefront is done reading the buffer that the next loads overwrite
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DNPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + DNBUF - 1 < nk) issue(kt + DNBUF - 1, (j + DNBUF - 1) % DNBUF);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();   // the tile buffers are free
+
+    // g/o wavefronts hand their accumulators to the i/f wavefront of the same unit half: [wj][gate][register][lane]
+    float* xch = lds;
+    if (wg == 1) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xch[((wj * 2 + g) * 16 + e) * 64 + lane] = acc[g][e];
+    }
+    __syncthreads();
+    if (wg == 1) return;
+    const int u = u0 + wj * 32 + r;
+    if (u >= a.Hd) return;
+    float bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = a.b_ih[g * a.Hd + u] + a.b_hh[g * a.Hd + u];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (i >= a.B) continue;
+        const float gi = acc[0][e] + bias[0], gf = acc[1][e] + bias[1];
+        const float gg = xch[((wj * 2 + 0) * 16 + e) * 64 + lane] + bias[2];
+        const float go = xch[((wj * 2 + 1) * 16 + e) * 64 + lane] + bias[3];
+        const float cp = a.c0 ? a.c0[(int64_t)i * a.Hd + u] : 0.f;
+        const float cn = sigmoidf_(gf) * cp + sigmoidf_(gi) * tanhf(gg);
+        const float hn = sigmoidf_(go) * tanhf(cn);
+        a.c1[(int64_t)i * a.Hd + u] = cn;
+        a.h1[(int64_t)i * a.ldh1 + u] = hn;
+        if (a.gates) {
+            float* gp = a.gates + (int64_t)i * 4 * a.Hd + u;
+            gp[0] = gi; gp[a.Hd] = gf; gp[2 * a.Hd] = gg; gp[3 * a.Hd] = go;
+        }
+    }
+}
+
 struct LstmBwdArgs {
     const float* gates; const float* c0; const float* c1;
     const float* dh_out; int64_t lddh; const float* dh_rec; const float* dc_in;
@@ -185,7 +318,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs a) {
     a.dc0[idx] = dc * sf;
 }
 
+int g_lstm_staging = 0;   // 0: automatic; 1: always the register-staged kernel (tests compare the two)
+
 }  // namespace
+
+extern "C" int capdec_lstm_force_staging(int mode) {
+    CAPDEC_REQUIRE(mode == 0 || mode == 1);
+    g_lstm_staging = mode;
+    return 0;
+}
 
 extern "C" int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, const float* w_ih,
                                 const float* w_hh, const float* b_ih, const float* b_hh, int B, int E, int Hd,
@@ -205,6 +346,16 @@ extern "C" int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, in
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
     if (!ready) return CAPDEC_EINVAL;
     dim3 grid((Hd + TU - 1) / TU, (B + TB - 1) / TB);
+    if (vec && E % BK == 0 && Hd % BK == 0 && g_lstm_staging != 1) {
+        constexpr size_t smem_dma = LSTM_DMA_LDS_FLOATS * sizeof(float);
+        static const bool ready_dma =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_dma_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dma) == hipSuccess;
+        if (!ready_dma) return CAPDEC_EINVAL;
+        hipLaunchKernelGGL(lstm_step_dma_kernel, grid, dim3(256), smem_dma, (hipStream_t)stream, a);
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
     if (vec) hipLaunchKernelGGL(lstm_step_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(lstm_step_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);
     CAPDEC_LAUNCH_CHECK();

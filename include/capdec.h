@@ -214,6 +214,9 @@ int capdec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, const float* w_ih,
                      const float* w_hh, const float* b_ih, const float* b_hh, int B, int E, int Hd, float* h1,
                      int64_t ldh1, float* c1, float* gates_out, void* stream);
+/* Tuning hook for tests and benchmarks: 0 = automatic, 1 = always the register-staged kernel (shapes with E and Hd
+ * multiples of 32 otherwise take the kernel whose loads write LDS directly).  Process-wide; not for production use. */
+int capdec_lstm_force_staging(int mode);
 
 /* Backward of one capdec_lstm_step (autograd of nn.LSTM inside DecoderRNN.forward, cnnrnn_model.py:29-30):
  * gates [B,4Hd] = the pre-activations saved by the forward step, c0 (NULL = zero) / c1 the cell state before /

@@ -202,6 +202,37 @@ def test_f9_lstm_step(ops):
     close(ca, cb, rtol=1e-6)
 
 
+@pytest.mark.parametrize("B,E,Hd", [(100, 256, 512), (33, 64, 96), (1024, 1024, 512)])
+def test_lstm_step_tiles_loaded_straight_into_lds(ops, B, E, Hd):
+    """E and Hd multiples of 32 take the kernel whose loads write LDS directly: against the fp64 cell equations
+    (cnnrnn_model.py:17,29-30: nn.LSTM, gates i,f,g,o) and bit for bit against the register-staged kernel."""
+    from capdec import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + E)
+    x, h0, c0 = (torch.randn(B, n, generator=g) for n in (E, Hd, Hd))
+    w_ih, w_hh = torch.randn(4 * Hd, E, generator=g) * E ** -0.5, torch.randn(4 * Hd, Hd, generator=g) * Hd ** -0.5
+    b_ih, b_hh = torch.randn(4 * Hd, generator=g), torch.randn(4 * Hd, generator=g)
+    gates = x.double() @ w_ih.double().t() + b_ih.double() + h0.double() @ w_hh.double().t() + b_hh.double()
+    gi, gf, gg, go = gates.split(Hd, dim=1)
+    c_ref = torch.sigmoid(gf) * c0.double() + torch.sigmoid(gi) * torch.tanh(gg)
+    h_ref = torch.sigmoid(go) * torch.tanh(c_ref)
+    args = [v.cuda() for v in (x, h0, c0, w_ih, w_hh, b_ih, b_hh)]
+    outs = []
+    try:
+        for staging in (1, 0):
+            lib.capdec_lstm_force_staging(staging)
+            h1, c1, gt = ops.lstm_step(*args, want_gates=True)
+            close(h1, h_ref, what=f"h staging {staging}")
+            close(c1, c_ref, what=f"c staging {staging}")
+            close(gt, gates, what=f"gates staging {staging}")
+            h1z, c1z = ops.lstm_step(args[0], None, None, *args[3:])
+            outs.append((h1, c1, gt, h1z, c1z))
+    finally:
+        lib.capdec_lstm_force_staging(0)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 # ---------------------------------------------------------------------------------------------
 # decoder_forward (teacher forced, inference) against golden logits
 # ---------------------------------------------------------------------------------------------
