@@ -27,7 +27,7 @@ class GemmGroup(Structure):
 
 class GemmExtra(Structure):
     _fields_ = [("mask", c_void_p), ("ldm", c_int64), ("lse", c_void_p), ("tgt", c_void_p), ("gscale", c_void_p),
-                ("ignore_index", c_int64), ("rows_dev", c_void_p)]
+                ("ignore_index", c_int64), ("rows_dev", c_void_p), ("k_dev", c_void_p)]
 
 
 class AttnW(Structure):
@@ -83,7 +83,10 @@ _SIGNATURES = {
     "capdec_add_layernorm_train": (c_int, [_P, c_int, _P, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
     "capdec_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P, _P]),
     "capdec_colsum": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
+    "capdec_colsum_rows": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P]),
     "capdec_softmax_nll_grad": (c_int, [_P, c_int64, _P, c_int, c_int, c_int64, _P, _P, _P, _P]),
+    "capdec_softmax_nll_grad_rows": (c_int, [_P, c_int64, _P, c_int, c_int, c_int64, _P, _P, _P, _P, _P]),
+    "capdec_compact_targets": (c_int, [_P, c_int, c_int64, _P, _P, _P, _P, _P]),
     "capdec_group_sum": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "capdec_embed_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "capdec_bn_train_backward": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),

@@ -8,7 +8,7 @@ pre-allocate (e.g. as views of one flat buffer for a single RCCL all-reduce and 
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 
 _SITE = 0x51ED2701  # odd stride between the dropout seeds of different sites
 
@@ -163,31 +163,57 @@ def vocab_logits_bwd(dec, x, dlogits, grads):
     return _lin_bwd(grads, "fc2", dec.fc2, dlogits, x)
 
 
-def vocab_loss(dec, x, targets, ignore_index=0, materialize=True):
+def vocab_loss(dec, x, targets, ignore_index=0, materialize=True, skip_ignored=True):
     """Projection + CrossEntropyLoss(ignore_index) (reference train.py:216,254-256).
     Returns (loss [1] device tensor, saved state for ``vocab_loss_bwd``).
 
     materialize=True (training): the logits are written once and turned in place into the softmax gradient, which
     the backward pass contracts with fc2 and x; on this machine writing and re-reading 4*M*V bytes is several times
-    cheaper than recomputing the M x V x E contraction.  materialize=False: fused log-sum-exp + NLL, no logits
-    (evaluation loss; its backward recomputes the projection tile-wise)."""
+    cheaper than recomputing the M x V x E contraction.  With skip_ignored the rows whose target is ``ignore_index``
+    (<PAD>: a quarter to a half of a padded caption batch) are moved behind the counted ones by a device-side
+    compaction and take no part in the projection, the softmax or the two backward contractions: their loss term and
+    every gradient through them are exactly zero in the reference too.  Nothing is synchronised: the number of
+    counted rows stays on the device and bounds the kernels' row and contraction ranges.
+    materialize=False: fused log-sum-exp + NLL, no logits (evaluation loss; its backward recomputes the projection
+    tile-wise)."""
     tg = targets.reshape(-1).contiguous()
+    if materialize and skip_ignored:
+        M = tg.numel()
+        order, slot, tg_c, count = ops.compact_targets(tg, ignore_index)
+        xc = x.index_select(0, order)
+        dlogits = torch.empty((M, dec.fc2.weight.shape[0]), device=x.device, dtype=torch.float32)
+        ops.gemm_raw(xc, dec.fc2.weight, dlogits, M, dlogits.shape[1], xc.shape[1], xc.stride(0), dec.fc2.weight.stride(0),
+                     bias_j=dec.fc2.bias, rows_dev=count)
+        sums, _ = ops.softmax_nll_grad_(dlogits, tg_c, ignore_index, rows_dev=count)
+        loss, _ = ops.loss_finish(sums)
+        return loss, ("compact", dlogits, xc, slot, count)
     if materialize:
         dlogits = ops.linear(x, dec.fc2.weight, dec.fc2.bias)
         sums, _ = ops.softmax_nll_grad_(dlogits, tg, ignore_index)
         loss, _ = ops.loss_finish(sums)
-        return loss, (dlogits,)
+        return loss, ("dense", dlogits)
     lse, nll, sums = ops.vocab_nll(x, dec.fc2.weight, dec.fc2.bias, tg, ignore_index)
     loss, gscale = ops.loss_finish(sums)
-    return loss, (lse, gscale, tg, ignore_index)
+    return loss, ("fused", lse, gscale, tg, ignore_index)
 
 
 def vocab_loss_bwd(dec, x, saved, grads):
     """d(loss)/dx and the fc2 gradients from what ``vocab_loss`` saved."""
-    if len(saved) == 1:
-        dlogits = saved[0]
+    if saved[0] == "compact":
+        _, dlogits, xc, slot, count = saved
+        M, E = xc.shape
+        W = dec.fc2.weight
+        ops.linear_wgrad(dlogits, xc, out=_new(grads, "fc2.weight", W), rows_dev=count)
+        if dec.fc2.bias is not None:
+            ops.colsum(dlogits, _new(grads, "fc2.bias", dec.fc2.bias), rows_dev=count)
+        # compacted d(loss)/dx with an all-zero extra row that the ignored rows pick up
+        dxc = torch.zeros((M + 1, E), device=x.device, dtype=torch.float32)
+        ops.gemm_raw(dlogits, W, dxc[:M], M, E, W.shape[0], dlogits.stride(0), W.stride(0), _lib.GEMM_TQ, rows_dev=count)
+        return dxc.index_select(0, slot)
+    if saved[0] == "dense":
+        dlogits = saved[1]
     else:
-        lse, gscale, targets, ignore_index = saved
+        _, lse, gscale, targets, ignore_index = saved
         dlogits = ops.softmax_grad_logits(x, dec.fc2.weight, dec.fc2.bias, lse, targets, gscale, ignore_index)
     return _lin_bwd(grads, "fc2", dec.fc2, dlogits, x)
 

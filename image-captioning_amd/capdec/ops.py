@@ -272,8 +272,9 @@ def vocab_nll(x, W, b, targets, ignore_index=0):
 # training-side ops
 # ---------------------------------------------------------------------------------------------
 def gemm_raw(P, Q, C, I, J, K, ldp, ldq, flags=0, bias_j=None, R=None, mask=None, lse=None, tgt=None, gscale=None,
-             ignore_index=0):
-    """Single-group contraction with explicit layout: see capdec_gemm_ex in capdec.h."""
+             ignore_index=0, rows_dev=None, k_dev=None):
+    """Single-group contraction with explicit layout: see capdec_gemm_ex in capdec.h.
+    rows_dev / k_dev: int32 device scalars limiting the output rows / the contraction length."""
     lib = _lib.load()
     g = (GemmGroup * 1)()
     g[0].P, g[0].Q, g[0].C = _chk(P).data_ptr(), _chk(Q).data_ptr(), _chk(C).data_ptr()
@@ -289,6 +290,10 @@ def gemm_raw(P, Q, C, I, J, K, ldp, ldq, flags=0, bias_j=None, R=None, mask=None
     if lse is not None:
         ex.lse, ex.tgt, ex.gscale, ex.ignore_index = (_chk(lse).data_ptr(), _chk(tgt, torch.int64).data_ptr(),
                                                        _chk(gscale).data_ptr(), ignore_index)
+    if rows_dev is not None:
+        ex.rows_dev = _chk(rows_dev, torch.int32, "rows_dev").data_ptr()
+    if k_dev is not None:
+        ex.k_dev = _chk(k_dev, torch.int32, "k_dev").data_ptr()
     _lib.check(lib.capdec_gemm_ex(g, 1, K, flags, byref(ex), _stream()), "capdec_gemm_ex")
     return C
 
@@ -301,24 +306,43 @@ def linear_dgrad(dy, W, mask=None, accum=None):
     return gemm_raw(dy, W, out, M, K, N, _row_stride(dy, "dy"), _row_stride(W, "W"), _lib.GEMM_TQ, R=accum, mask=mask)
 
 
-def linear_wgrad(dy, x, out=None):
+def linear_wgrad(dy, x, out=None, rows_dev=None):
     """dW += dY^T X  (dY [M,N], X [M,K]) -> [N,K].  The contraction over the M rows is split over workgroups and
-    summed with float atomics, so ``out`` is accumulated into (a fresh zero tensor when omitted)."""
+    summed with float atomics, so ``out`` is accumulated into (a fresh zero tensor when omitted).
+    rows_dev: int32 device scalar; only the first rows_dev[0] rows are contracted (dY must hold zeros, X anything
+    finite, from there up to the next multiple of 32)."""
     M, N = dy.shape
     K = x.shape[1]
     if out is None:
         out = torch.zeros((N, K), device=dy.device, dtype=torch.float32)
     return gemm_raw(dy, x, out, N, K, M, _row_stride(dy, "dy"), _row_stride(x, "x"),
-                    _lib.GEMM_TP | _lib.GEMM_TQ | _lib.GEMM_ATOMIC)
+                    _lib.GEMM_TP | _lib.GEMM_TQ | _lib.GEMM_ATOMIC, k_dev=rows_dev)
 
 
-def colsum(x, out):
-    """out[j] += sum_i x[i,j]"""
+def colsum(x, out, rows_dev=None):
+    """out[j] += sum_i x[i,j]  (over the first rows_dev[0] rows when that int32 device scalar is given)"""
     lib = _lib.load()
     M, N = x.shape
-    _lib.check(lib.capdec_colsum(_chk(x).data_ptr(), _row_stride(x, "x"), M, N, _chk(out).data_ptr(), _stream()),
-               "capdec_colsum")
+    _lib.check(lib.capdec_colsum_rows(_chk(x).data_ptr(), _row_stride(x, "x"), M, N, _chk(out).data_ptr(),
+                                      _ptr(rows_dev), _stream()), "capdec_colsum_rows")
     return out
+
+
+def compact_targets(targets, ignore_index=0):
+    """Rows with a counted target first (stable).  targets [M] int64 ->
+    (order int64 [M]: row of slot s, slot int64 [M]: slot of row r or M if ignored, targets_c int64 [M], count int32 [1])."""
+    lib = _lib.load()
+    _chk(targets, torch.int64, "targets")
+    if not targets.is_contiguous() or targets.dim() != 1:
+        raise RuntimeError("capdec compact_targets: targets must be a contiguous [M] tensor")
+    M = targets.numel()
+    order = torch.empty(M, device=targets.device, dtype=torch.int64)
+    slot = torch.empty(M, device=targets.device, dtype=torch.int64)
+    tgt_c = torch.empty(M, device=targets.device, dtype=torch.int64)
+    count = torch.empty(1, device=targets.device, dtype=torch.int32)
+    _lib.check(lib.capdec_compact_targets(targets.data_ptr(), M, ignore_index, order.data_ptr(), slot.data_ptr(),
+                                          tgt_c.data_ptr(), count.data_ptr(), _stream()), "capdec_compact_targets")
+    return order, slot, tgt_c, count
 
 
 def group_sum(x, T):
@@ -435,8 +459,9 @@ def softmax_grad_logits(x, W, b, lse, targets, gscale, ignore_index=0, out=None)
                     gscale=gscale, ignore_index=ignore_index)
 
 
-def softmax_nll_grad_(logits, targets, ignore_index=0):
-    """In place: logits [M,V] -> d(mean NLL)/d(logits).  Returns (sums [2] = (sum nll, n counted), gscale [1])."""
+def softmax_nll_grad_(logits, targets, ignore_index=0, rows_dev=None):
+    """In place: logits [M,V] -> d(mean NLL)/d(logits).  Returns (sums [2] = (sum nll, n counted), gscale [1]).
+    rows_dev: int32 device scalar; only the first rows_dev[0] rows hold logits (see capdec_softmax_nll_grad_rows)."""
     lib = _lib.load()
     _chk(logits, name="logits")
     _chk(targets, torch.int64, "targets")
@@ -445,9 +470,9 @@ def softmax_nll_grad_(logits, targets, ignore_index=0):
         raise RuntimeError("capdec softmax_nll_grad_: targets must be a contiguous [M] tensor")
     sums = torch.zeros(2, device=logits.device, dtype=torch.float32)
     gscale = torch.empty(1, device=logits.device, dtype=torch.float32)
-    _lib.check(lib.capdec_softmax_nll_grad(logits.data_ptr(), _row_stride(logits, "logits"), targets.data_ptr(), M, V,
-                                           ignore_index, sums.data_ptr(), gscale.data_ptr(), None, _stream()),
-               "capdec_softmax_nll_grad")
+    _lib.check(lib.capdec_softmax_nll_grad_rows(logits.data_ptr(), _row_stride(logits, "logits"), targets.data_ptr(), M,
+                                                V, ignore_index, sums.data_ptr(), gscale.data_ptr(), None,
+                                                _ptr(rows_dev), _stream()), "capdec_softmax_nll_grad_rows")
     return sums, gscale
 
 

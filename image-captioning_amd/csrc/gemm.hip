@@ -497,12 +497,15 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
     // rows_dev: the number of live rows is only known on the device (decode steps that re-run a few rows)
     const int nI = args.x.rows_dev ? min(g.I, args.x.rows_dev[0]) : g.I;
     if (i0 >= nI || j0 >= g.J) return;   // groups of different size share the grid
-    const int nk = (args.K + BK - 1) / BK;
+    // k_dev: the contraction length is only known on the device (rows compacted by a kernel); whole k-tiles are
+    // read, so the operands hold zeros (or anything finite against zeros) up to the next multiple of BK
+    const int K = args.x.k_dev ? min(args.K, args.x.k_dev[0]) : args.K;
+    const int nk = (K + BK - 1) / BK;
     const int per = (nk + args.nsplit - 1) / args.nsplit;
     const int kt0 = split * per, kt1 = min(nk, kt0 + per);
     f32x16 acc[WI][WJ];
     if (DMA) mainloop_dma<WM, WI, WJ, BK, dma_cut<BK, KG>(), dma_nbuf<KG>(), TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, nI, g.J, i0, j0, kt0, kt1, lds, acc);
-    else mainloop<WM, WI, WJ, BK, VEC, TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, nI, g.J, args.K, i0, j0, kt0, kt1, lds, acc);
+    else mainloop<WM, WI, WJ, BK, VEC, TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, nI, g.J, K, i0, j0, kt0, kt1, lds, acc);
     if (KG > 1 && threadIdx.x >= 128 * WM) return;   // group 0 holds the summed tile
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -232,11 +232,13 @@ constexpr int CS_ROWS = 256;
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, const int32_t* __restrict__ rows_dev) {
     __shared__ f32x4 red[16][16];
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int j = blockIdx.x * 64 + cl * 4;
     const int r0 = blockIdx.y * CS_ROWS;
+    if (rows_dev) M = min(M, rows_dev[0]);
+    if (r0 >= M) return;
     const int r1 = min(M, r0 + CS_ROWS);
     f32x4 s[8];
 #pragma unroll
@@ -814,16 +816,31 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void softmax_nll_grad_kernel(float* __restrict__ logits, int64_t ld,
                                                                const int64_t* __restrict__ targets, int M, int V,
                                                                int64_t ignore_index, float* __restrict__ gscale,
-                                                               float* __restrict__ sums, float* __restrict__ lse_out) {
+                                                               float* __restrict__ sums, float* __restrict__ lse_out,
+                                                               const int32_t* __restrict__ rows_dev) {
     __shared__ float red[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float gs = 1.0f / sums[1];            // complete: the counting kernel ran before this one
     if (blockIdx.x == 0 && threadIdx.x == 0) gscale[0] = gs;
+    // rows_dev: only the first rows_dev[0] rows hold logits; the rows up to the next multiple of 32 are zeroed (a
+    // contraction over the rows reads whole k-tiles) and the rest is left alone
+    const int live = rows_dev ? min(M, rows_dev[0]) : M;
+    const int upto = rows_dev ? min(M, (live + 31) / 32 * 32) : M;
     float acc = 0.f;
     for (int rr = wave; rr < SM_ROWS; rr += 4) {
         const int row = blockIdx.x * SM_ROWS + rr;
-        if (row >= M) break;
+        if (row >= upto) break;
         float* lr = logits + (int64_t)row * ld;
+        if (row >= live || (!lse_out && targets[row] == ignore_index)) {
+            // no gradient and no log-sum-exp wanted: the row is not read
+            if (VEC) {
+                f32x4* l4 = reinterpret_cast<f32x4*>(lr);
+                for (int c = lane; c < V / 4; c += 64) l4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                for (int c = lane; c < V; c += 64) lr[c] = 0.f;
+            }
+            continue;
+        }
         float mx = -INFINITY, sm = 0.f;
         if (VEC) {
             const f32x4* l4 = reinterpret_cast<const f32x4*>(lr);
@@ -876,6 +893,47 @@ __global__ __launch_bounds__(256) void softmax_nll_grad_kernel(float* __restrict
         const float t = red[0] + red[1] + red[2] + red[3];
         if (t != 0.f) atomicAdd(&sums[0], t);
     }
+}
+
+
+// ---- rows with a counted target first ------------------------------------------------------------------------
+// One workgroup: thread t owns the rows [t*per, (t+1)*per); an exclusive scan over the threads' counts places
+// them, so the order of the counted rows is kept.
+__global__ __launch_bounds__(1024) void compact_targets_kernel(const int64_t* __restrict__ targets, int M,
+                                                               int64_t ignore_index, int64_t* __restrict__ order,
+                                                               int64_t* __restrict__ slot, int64_t* __restrict__ tgt_c,
+                                                               int32_t* __restrict__ count) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (M + 1023) / 1024;
+    const int lo = min(M, t * per), hi = min(M, lo + per);
+    int n = 0;
+    for (int r = lo; r < hi; ++r) n += targets[r] != ignore_index;
+    part[t] = n;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {          // inclusive scan
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const int total = part[1023];
+    int at = part[t] - n;
+    for (int r = lo; r < hi; ++r) {
+        const int64_t tg = targets[r];
+        if (tg != ignore_index) {
+            order[at] = r;
+            tgt_c[at] = tg;
+            slot[r] = at++;
+        } else {
+            slot[r] = M;                          // the caller's all-zero extra row
+        }
+    }
+    for (int r = total + t; r < M; r += 1024) {   // unused slots: any valid row, never a counted target
+        order[r] = 0;
+        tgt_c[r] = ignore_index;
+    }
+    if (t == 0) count[0] = total;
 }
 
 }  // namespace
@@ -934,15 +992,19 @@ int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, con
     return 0;
 }
 
-int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream) {
+int capdec_colsum_rows(const float* x, int64_t ldx, int M, int N, float* out, const int32_t* rows_dev, void* stream) {
     CAPDEC_REQUIRE(x && out && M >= 0 && N >= 1 && ldx >= N);
     if (M == 0) return 0;
     const bool vec = N % 4 == 0 && ldx % 4 == 0 && capdec_aligned16(x);
     dim3 grid((N + 63) / 64, (M + CS_ROWS - 1) / CS_ROWS);
-    if (vec) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, out);
-    else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, out);
+    if (vec) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, out, rows_dev);
+    else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, M, N, out, rows_dev);
     CAPDEC_LAUNCH_CHECK();
     return 0;
+}
+
+int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream) {
+    return capdec_colsum_rows(x, ldx, M, N, out, nullptr, stream);
 }
 
 int capdec_group_sum(const float* x, int G, int T, int E, float* out, void* stream) {
@@ -1055,6 +1117,11 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
 
 int capdec_softmax_nll_grad(float* logits, int64_t ld, const int64_t* targets, int M, int V, int64_t ignore_index,
                             float* sums, float* gscale, float* lse_out, void* stream) {
+    return capdec_softmax_nll_grad_rows(logits, ld, targets, M, V, ignore_index, sums, gscale, lse_out, nullptr, stream);
+}
+
+int capdec_softmax_nll_grad_rows(float* logits, int64_t ld, const int64_t* targets, int M, int V, int64_t ignore_index,
+                                 float* sums, float* gscale, float* lse_out, const int32_t* rows_dev, void* stream) {
     CAPDEC_REQUIRE(logits && targets && sums && gscale && M >= 0 && V >= 1 && ld >= V);
     if (M == 0) return 0;
     const int count_grid = M >= 16 * 256 ? 16 : (M + 255) / 256;
@@ -1064,10 +1131,20 @@ int capdec_softmax_nll_grad(float* logits, int64_t ld, const int64_t* targets, i
     const dim3 grid((M + SM_ROWS - 1) / SM_ROWS);
     if (vec)
         hipLaunchKernelGGL(softmax_nll_grad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, logits, ld, targets, M,
-                           V, ignore_index, gscale, sums, lse_out);
+                           V, ignore_index, gscale, sums, lse_out, rows_dev);
     else
         hipLaunchKernelGGL(softmax_nll_grad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, logits, ld, targets, M,
-                           V, ignore_index, gscale, sums, lse_out);
+                           V, ignore_index, gscale, sums, lse_out, rows_dev);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_compact_targets(const int64_t* targets, int M, int64_t ignore_index, int64_t* order, int64_t* slot,
+                           int64_t* targets_c, int32_t* count, void* stream) {
+    CAPDEC_REQUIRE(targets && order && slot && targets_c && count && M >= 0);
+    if (M == 0) return (int)hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream);
+    hipLaunchKernelGGL(compact_targets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, targets, M, ignore_index, order,
+                       slot, targets_c, count);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

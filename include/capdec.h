@@ -80,6 +80,9 @@ typedef struct capdec_gemm_extra {
     const float* mask; int64_t ldm;
     const float* lse; const int64_t* tgt; const float* gscale; int64_t ignore_index;
     const int32_t* rows_dev;   /* nullable device scalar: only rows i < min(I, rows_dev[0]) are computed */
+    const int32_t* k_dev;      /* nullable device scalar: the contraction runs over k < min(K, k_dev[0]) only; whole
+                                  32-deep k-tiles are read, so both operands must hold zeros (or finite values against
+                                  zeros) from k_dev[0] up to the next multiple of 32 */
 } capdec_gemm_extra;
 /* Tuning hook for benchmarks: 0 = automatic tile choice, 11 / 116 = 64x64 (BK 32 / 16), 22 / 216 = 128x128 (BK 32 / 16),
  * 32 = 32x64 tile with its k-loop split over the two wave pairs.  Process-wide; not for production use. */
@@ -173,6 +176,8 @@ int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, con
                          float* dxsum, void* stream);
 /* out[j] += sum_i x[i*ldx + j] */
 int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream);
+/* The same over the first min(M, rows_dev[0]) rows (rows_dev: nullable device scalar). */
+int capdec_colsum_rows(const float* x, int64_t ldx, int M, int N, float* out, const int32_t* rows_dev, void* stream);
 /* out[g,:] = sum over t < T of x[g*T + t, :]  (gradient of a row that was broadcast over T positions) */
 int capdec_group_sum(const float* x, int G, int T, int E, float* out, void* stream);
 /* demb[ids[r],:] += dx[r,:]  (nn.Embedding backward, transformer.py:126 / cnnrnn_model.py:27) */
@@ -199,6 +204,16 @@ int capdec_attention_bwd_force_two_pass(int on);
  * sums[0] += sum of the rows' NLL, sums[1] = n_counted; gscale[0] = 1 / n_counted; lse_out [M] nullable. */
 int capdec_softmax_nll_grad(float* logits, int64_t ld, const int64_t* targets, int M, int V, int64_t ignore_index,
                             float* sums, float* gscale, float* lse_out, void* stream);
+/* The same when only the first rows_dev[0] rows hold logits (rows_dev: nullable device scalar): those rows are
+ * processed, the rows up to the next multiple of 32 are zeroed, the rest is left untouched. */
+int capdec_softmax_nll_grad_rows(float* logits, int64_t ld, const int64_t* targets, int M, int V, int64_t ignore_index,
+                                 float* sums, float* gscale, float* lse_out, const int32_t* rows_dev, void* stream);
+/* Rows with a counted target first (the loss of train.py:216,254-256 ignores <PAD> targets, so their logits, and
+ * the three vocabulary-sized contractions over them, need not be computed; the reference computes and discards them).
+ * Stable.  order [M]: row of slot s (slots >= count name row 0); slot [M]: slot of row r, or M for an ignored row;
+ * targets_c [M]: targets[order[s]] (ignore_index from slot count on); count [1]: number of counted targets. */
+int capdec_compact_targets(const int64_t* targets, int M, int64_t ignore_index, int64_t* order, int64_t* slot,
+                           int64_t* targets_c, int32_t* count, void* stream);
 /* sums = (sum of nll, number of counted targets) from capdec_nll_finalize:
  * loss[0] = sums[0] / sums[1] (nn.CrossEntropyLoss mean over non-ignored targets), gscale[0] = 1 / sums[1] */
 int capdec_loss_finish(const float* sums, float* loss, float* gscale, void* stream);

@@ -58,8 +58,9 @@ def test_f4_logits_loss_and_all_gradients_via_autograd(S):
             assert float(dec.decoder_layers[l].cross_attn.W_k.weight.grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("S,shortcut,materialize", [(1, True, True), (1, False, False), (5, True, False), (5, True, True)])
-def test_f4_fused_loss_path(S, shortcut, materialize):
+@pytest.mark.parametrize("S,shortcut,materialize,skip", [(1, True, True, True), (1, False, False, False), (5, True, False, False),
+                                                         (5, True, True, True), (5, True, True, False)])
+def test_f4_fused_loss_path(S, shortcut, materialize, skip):
     """Projection + log-sum-exp + NLL without logits, and its backward, against the same golden vectors; with one
     memory row both the closed form of the cross-attention sub-layer and the general kernels are checked."""
     from capdec import autograd as AG
@@ -68,7 +69,7 @@ def test_f4_fused_loss_path(S, shortcut, materialize):
     caps = t(fx["captions"]).cuda()
     enc = t(fx[f"enc_S{S}"]).cuda()
     x, tape = AG.tf_forward(dec, enc, caps[:, :-1].contiguous(), 0.0, 0, single_row_shortcut=shortcut)
-    loss, saved = AG.vocab_loss(dec, x, caps[:, 1:].contiguous(), materialize=materialize)
+    loss, saved = AG.vocab_loss(dec, x, caps[:, 1:].contiguous(), materialize=materialize, skip_ignored=skip)
     close(loss[0], fx[f"loss_S{S}"], rtol=1e-5, what="loss")
     grads = {}
     dx = AG.vocab_loss_bwd(dec, x, saved, grads)
@@ -78,6 +79,43 @@ def test_f4_fused_loss_path(S, shortcut, materialize):
     atol = _noise_floor(fx, "grad__{}@S" + str(S), names)
     for name in names:
         close(grads[name], fx[f"grad__{name}@S{S}"], atol=atol, what=name)
+
+
+@pytest.mark.parametrize("M,frac_pad", [(70, 0.4), (1000, 0.3), (333, 1.0), (257, 0.0), (4096, 0.5)])
+def test_vocab_loss_skips_ignored_rows(M, frac_pad):
+    """Rows with an ignored target are compacted away on the device (no host sync): loss, d(loss)/dx and the fc2
+    gradients against nn.CrossEntropyLoss(ignore_index=0) in fp64 (train.py:216,254-256) and against the dense path."""
+    from capdec import autograd as AG
+    g = torch.Generator().manual_seed(M)
+    E, V = 64, 300
+    fc2 = torch.nn.Linear(E, V)
+    holder = type("Holder", (), {})()
+    holder.fc2 = fc2.cuda()
+    x = torch.randn(M, E, generator=g)
+    tgt = torch.randint(1, V, (M,), generator=g)
+    tgt[torch.rand(M, generator=g) < frac_pad] = 0
+    if frac_pad >= 1.0:
+        tgt[:] = 0
+    xd = x.double().requires_grad_(True)
+    Wd, bd = fc2.weight.detach().double().cpu().requires_grad_(True), fc2.bias.detach().double().cpu().requires_grad_(True)
+    outs = {}
+    for skip in (True, False):
+        grads = {}
+        loss, saved = AG.vocab_loss(holder, x.cuda(), tgt.cuda(), skip_ignored=skip)
+        dx = AG.vocab_loss_bwd(holder, x.cuda(), saved, grads)
+        outs[skip] = (loss, dx, grads["fc2.weight"], grads["fc2.bias"])
+    if frac_pad >= 1.0:      # no counted target: the reference's mean over zero terms is NaN; every gradient is NaN or 0
+        assert not torch.isfinite(outs[True][0]).any() and not torch.isfinite(outs[False][0]).any()
+        return
+    ref = torch.nn.functional.cross_entropy(xd @ Wd.t() + bd, tgt, ignore_index=0)
+    ref.backward()
+    for skip in (True, False):
+        loss, dx, dw, db = outs[skip]
+        close(loss[0], ref.detach(), rtol=1e-5, what=f"loss skip={skip}")
+        close(dx, xd.grad, what=f"dx skip={skip}")
+        close(dw, Wd.grad, what=f"dW skip={skip}")
+        close(db, bd.grad, what=f"db skip={skip}")
+    assert float(outs[True][1][tgt == 0].abs().max() if (tgt == 0).any() else 0.0) == 0.0
 
 
 def test_f6_cnn_attn_train_mode_batchnorm_and_head_gradients():
