@@ -95,6 +95,16 @@ _SIGNATURES = {
                                      _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
     "capdec_loss_finish": (c_int, [_P, _P, _P, _P]),
+    "capdec_add_layernorm_train_rows": (c_int, [_P, c_int, _P, _P, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P,
+                                                _P, _P, _P, _P]),
+    "capdec_layernorm_bwd_rows": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P, _P, _P]),
+    "capdec_group_sum_segments": (c_int, [_P, c_int, _P, c_int, _P, _P]),
+    "capdec_embed_bwd_rows": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "capdec_compact_prefix": (c_int, [_P, _P, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "capdec_attention_ragged": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, _P,
+                                        _P, _P, _P]),
+    "capdec_attention_bwd_ragged": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64,
+                                            _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "capdec_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "capdec_bn_fold": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
     "capdec_bn_train_forward": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, c_int, c_int, _P, _P, _P, _P]),

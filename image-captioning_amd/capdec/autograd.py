@@ -31,23 +31,37 @@ def _new(grads, name, like):
     return g
 
 
-def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None, bias_done=False):
+def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None, bias_done=False, rows=None):
     """Backward of y = x W^T + b: fills grads[prefix.weight/.bias]; returns dX (added onto ``accum`` if given).
-    bias_done: the bias gradient was already accumulated by the kernel that produced dy."""
-    ops.linear_wgrad(dy, x, out=_new(grads, prefix + ".weight", lin.weight))
+    bias_done: the bias gradient was already accumulated by the kernel that produced dy.
+    rows: int32 device scalar (a multiple of 32); only the first rows[0] rows of dy and x exist."""
+    ops.linear_wgrad(dy, x, out=_new(grads, prefix + ".weight", lin.weight), rows_dev=rows)
     if lin.bias is not None and not bias_done:
-        ops.colsum(dy, _new(grads, prefix + ".bias", lin.bias))
+        ops.colsum(dy, _new(grads, prefix + ".bias", lin.bias), rows_dev=rows)
     if need_dx:
-        return ops.linear_dgrad(dy, lin.weight, mask=mask, accum=accum)
+        return ops.linear_dgrad(dy, lin.weight, mask=mask, accum=accum, rows_dev=rows)
     return None
 
 
 # ---------------------------------------------------------------------------------------------
 # Transformer decoder stack
 # ---------------------------------------------------------------------------------------------
-def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True):
+def ragged_supported(dec, S, T, single_row_shortcut=True):
+    """Whether ``tf_forward`` can run on the live rows only: one memory row (the cross-attention sub-layer is then a
+    per-sample constant) and sequences short enough for the one-workgroup attention kernels."""
+    E, H = dec.decoder_embedding.weight.shape[1], dec.num_heads
+    dk = E // H
+    return (S == 1 and single_row_shortcut and T <= 64 and dk in (16, 32, 64, 128, 256) and
+            (4 * T * (dk + 16) + 2 * T * T) * 4 <= 144 * 1024)
+
+
+def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
     """Teacher-forced decoder stack (reference transformer.py:125-132) keeping what the backward needs.
-    enc [B,S,E] fp32, ids [B,T] int64.  Returns (x [B*T,E] post-LN output of the last layer, tape)."""
+    enc [B,S,E] fp32, ids [B,T] int64.  Returns (x [B*T,E] post-LN output of the last layer, tape).
+
+    ragged (ops.RaggedRows of the same ids and their targets; needs ``ragged_supported``): the stack runs on the live
+    rows only.  Every [B*T,E] tensor is then indexed by slot, the first ``ragged.rows[0]`` rows exist, and the caller
+    takes the loss against ``ragged.targets_c`` with that row limit.  The dropout masks are drawn per slot."""
     B, S, E = enc.shape
     T = ids.shape[1]
     M, H = B * T, dec.num_heads
@@ -61,6 +75,14 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True):
     if T > pe.shape[0]:
         raise RuntimeError(f"capdec: sequence length {T} exceeds the positional-encoding buffer ({pe.shape[0]})")
     x = ops.embed_pe(t.ids, dec.decoder_embedding.weight, pe)
+    t.ragged = ragged
+    rows = None
+    if ragged is not None:
+        if not ragged_supported(dec, S, T, single_row_shortcut) or (ragged.B, ragged.T) != (B, T):
+            raise RuntimeError("capdec tf_forward: this configuration cannot run on a ragged batch (see ragged_supported)")
+        rows = ragged.rows
+        x = x.index_select(0, ragged.order)
+        t.ids_c = t.ids.view(-1).index_select(0, ragged.order)
     if p > 0:
         x = ops.dropout(x, p, seed)
     t.layers = []
@@ -72,18 +94,22 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True):
         qkv = torch.empty((3, M, E), device=x.device, dtype=torch.float32)
         ops.gemm_groups([dict(P=x, Q=sa.W_q.weight, C=qkv[0], bias_j=sa.W_q.bias),
                          dict(P=x, Q=sa.W_k.weight, C=qkv[1], bias_j=sa.W_k.bias),
-                         dict(P=x, Q=sa.W_v.weight, C=qkv[2], bias_j=sa.W_v.bias)], E)
+                         dict(P=x, Q=sa.W_v.weight, C=qkv[2], bias_j=sa.W_v.bias)], E, rows_dev=rows)
         c.qkv = qkv
-        c.ao, c.lse = ops.attention(qkv[0], qkv[1], qkv[2], B, H, T, T, causal=True, ids32=t.ids32, want_lse=True)
-        a = ops.linear(c.ao, sa.W_o.weight, sa.W_o.bias)
-        c.x1, c.s1, c.m1, c.r1 = ops.add_layernorm_train(a, x, ly.norm1.weight, ly.norm1.bias, p, sd)
+        if ragged is not None:
+            c.ao, c.lse = ops.attention_ragged(qkv[0], qkv[1], qkv[2], ragged, H, want_lse=True)
+        else:
+            c.ao, c.lse = ops.attention(qkv[0], qkv[1], qkv[2], B, H, T, T, causal=True, ids32=t.ids32, want_lse=True)
+        a = ops.linear(c.ao, sa.W_o.weight, sa.W_o.bias, rows_dev=rows)
+        c.x1, c.s1, c.m1, c.r1 = ops.add_layernorm_train(a, x, ly.norm1.weight, ly.norm1.bias, p, sd, rows_dev=rows)
         if S == 1 and single_row_shortcut:
             # one memory row: the softmax over it is exactly 1, so the sub-layer output is W_o(W_v enc + b_v) + b_o
             # for every position, whatever the query (reference transformer.py:13-22 with Tk = 1)
             c.v2 = ops.linear(t.enc, ca.W_v.weight, ca.W_v.bias)                       # [B,E]
             c.cc = ops.linear(c.v2, ca.W_o.weight, ca.W_o.bias)                        # [B,E]
             c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(c.cc, c.x1, ly.norm2.weight, ly.norm2.bias, p,
-                                                             sd + _SITE, x_div=T)
+                                                             sd + _SITE, x_div=T, rows_dev=rows,
+                                                             x_map=None if ragged is None else ragged.sample)
         else:
             c.q2 = ops.linear(c.x1, ca.W_q.weight, ca.W_q.bias)
             kv2 = torch.empty((2, B * S, E), device=x.device, dtype=torch.float32)
@@ -93,9 +119,10 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True):
             c.ao2, c.lse2 = ops.attention(c.q2, kv2[0], kv2[1], B, H, T, S, want_lse=True)
             a2 = ops.linear(c.ao2, ca.W_o.weight, ca.W_o.bias)
             c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(a2, c.x1, ly.norm2.weight, ly.norm2.bias, p, sd + _SITE)
-        c.h = ops.linear(c.x2, ff.fc1.weight, ff.fc1.bias, relu=True)
-        f = ops.linear(c.h, ff.fc2.weight, ff.fc2.bias)
-        x, c.s3, c.m3, c.r3 = ops.add_layernorm_train(f, c.x2, ly.norm3.weight, ly.norm3.bias, p, sd + 2 * _SITE)
+        c.h = ops.linear(c.x2, ff.fc1.weight, ff.fc1.bias, relu=True, rows_dev=rows)
+        f = ops.linear(c.h, ff.fc2.weight, ff.fc2.bias, rows_dev=rows)
+        x, c.s3, c.m3, c.r3 = ops.add_layernorm_train(f, c.x2, ly.norm3.weight, ly.norm3.bias, p, sd + 2 * _SITE,
+                                                      rows_dev=rows)
         t.layers.append(c)
     t.out = x
     return x, t
@@ -105,6 +132,8 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
     """Backward of ``tf_forward``.  dx [B*T,E].  Fills ``grads`` (keys = names under ``dec``); returns denc
     [B,S,E] (or None)."""
     B, S, T, E, H, p = t.B, t.S, t.T, t.E, t.H, t.p
+    rg = t.ragged
+    rows = None if rg is None else rg.rows
     denc = torch.zeros((B * S, E), device=dx.device, dtype=torch.float32) if need_denc else None
     for l in range(len(t.layers) - 1, -1, -1):
         ly, c = dec.decoder_layers[l], t.layers[l]
@@ -117,16 +146,16 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         d_x2, d_f = ops.layernorm_bwd(dx, c.s3, c.m3, c.r3, ly.norm3.weight, p, sd + 2 * _SITE,
                                       _new(grads, pre + "norm3.weight", ly.norm3.weight),
                                       _new(grads, pre + "norm3.bias", ly.norm3.bias),
-                                      dxsum=_new(grads, pre + "feed_forward.fc2.bias", ff.fc2.bias))
-        dh = _lin_bwd(grads, pre + "feed_forward.fc2", ff.fc2, d_f, c.h, mask=c.h, bias_done=True)   # ReLU backward fused
-        _lin_bwd(grads, pre + "feed_forward.fc1", ff.fc1, dh, c.x2, accum=d_x2)
+                                      dxsum=_new(grads, pre + "feed_forward.fc2.bias", ff.fc2.bias), rows_dev=rows)
+        dh = _lin_bwd(grads, pre + "feed_forward.fc2", ff.fc2, d_f, c.h, mask=c.h, bias_done=True, rows=rows)   # ReLU backward fused
+        _lin_bwd(grads, pre + "feed_forward.fc1", ff.fc1, dh, c.x2, accum=d_x2, rows=rows)
         # x2 = LN2(x1 + drop(a2)),  a2 = attn(x1 Wq, enc Wk, enc Wv) Wo
         d_x1, d_a2 = ops.layernorm_bwd(d_x2, c.s2, c.m2, c.r2, ly.norm2.weight, p, sd + _SITE,
                                        _new(grads, pre + "norm2.weight", ly.norm2.weight),
                                        _new(grads, pre + "norm2.bias", ly.norm2.bias),
-                                       dxsum=_new(grads, pre + "cross_attn.W_o.bias", ca.W_o.bias))
+                                       dxsum=_new(grads, pre + "cross_attn.W_o.bias", ca.W_o.bias), rows_dev=rows)
         if t.shortcut:
-            d_cc = ops.group_sum(d_a2, T)                                              # [B,E]
+            d_cc = ops.group_sum(d_a2, T) if rg is None else ops.group_sum_segments(d_a2, rg.seq_off, B)   # [B,E]
             d_v2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_cc, c.v2, bias_done=True)
             _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, d_v2, t.enc, need_dx=need_denc, accum=denc)
             for n, prm in (("W_q.weight", ca.W_q.weight), ("W_q.bias", ca.W_q.bias), ("W_k.weight", ca.W_k.weight),
@@ -142,19 +171,23 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         d_x, d_a = ops.layernorm_bwd(d_x1, c.s1, c.m1, c.r1, ly.norm1.weight, p, sd,
                                      _new(grads, pre + "norm1.weight", ly.norm1.weight),
                                      _new(grads, pre + "norm1.bias", ly.norm1.bias),
-                                     dxsum=_new(grads, pre + "self_attn.W_o.bias", sa.W_o.bias))
-        d_ao = _lin_bwd(grads, pre + "self_attn.W_o", sa.W_o, d_a, c.ao, bias_done=True)
-        dq, dk, dv = ops.attention_bwd(c.qkv[0], c.qkv[1], c.qkv[2], d_ao, c.lse, B, H, T, T, causal=True,
-                                       ids32=t.ids32)
-        _lin_bwd(grads, pre + "self_attn.W_q", sa.W_q, dq, c.x, accum=d_x)
-        _lin_bwd(grads, pre + "self_attn.W_k", sa.W_k, dk, c.x, accum=d_x)
-        _lin_bwd(grads, pre + "self_attn.W_v", sa.W_v, dv, c.x, accum=d_x)
+                                     dxsum=_new(grads, pre + "self_attn.W_o.bias", sa.W_o.bias), rows_dev=rows)
+        d_ao = _lin_bwd(grads, pre + "self_attn.W_o", sa.W_o, d_a, c.ao, bias_done=True, rows=rows)
+        if rg is not None:
+            dq, dk, dv = ops.attention_bwd_ragged(c.qkv[0], c.qkv[1], c.qkv[2], d_ao, c.lse, rg, H)
+        else:
+            dq, dk, dv = ops.attention_bwd(c.qkv[0], c.qkv[1], c.qkv[2], d_ao, c.lse, B, H, T, T, causal=True,
+                                           ids32=t.ids32)
+        _lin_bwd(grads, pre + "self_attn.W_q", sa.W_q, dq, c.x, accum=d_x, rows=rows)
+        _lin_bwd(grads, pre + "self_attn.W_k", sa.W_k, dk, c.x, accum=d_x, rows=rows)
+        _lin_bwd(grads, pre + "self_attn.W_v", sa.W_v, dv, c.x, accum=d_x, rows=rows)
         dx = d_x
         if on_layer_done is not None:
             on_layer_done(l)          # every gradient of layer l is now enqueued
     if p > 0:
         dx = ops.dropout(dx, p, t.seed)
-    ops.embed_bwd(t.ids.view(-1), dx, _new(grads, "decoder_embedding.weight", dec.decoder_embedding.weight))
+    ops.embed_bwd(t.ids.view(-1) if rg is None else t.ids_c, dx,
+                  _new(grads, "decoder_embedding.weight", dec.decoder_embedding.weight), rows_dev=rows)
     return denc.view(B, S, E) if need_denc else None
 
 
@@ -163,7 +196,7 @@ def vocab_logits_bwd(dec, x, dlogits, grads):
     return _lin_bwd(grads, "fc2", dec.fc2, dlogits, x)
 
 
-def vocab_loss(dec, x, targets, ignore_index=0, materialize=True, skip_ignored=True):
+def vocab_loss(dec, x, targets, ignore_index=0, materialize=True, skip_ignored=True, rows=None):
     """Projection + CrossEntropyLoss(ignore_index) (reference train.py:216,254-256).
     Returns (loss [1] device tensor, saved state for ``vocab_loss_bwd``).
 
@@ -177,6 +210,15 @@ def vocab_loss(dec, x, targets, ignore_index=0, materialize=True, skip_ignored=T
     materialize=False: fused log-sum-exp + NLL, no logits (evaluation loss; its backward recomputes the projection
     tile-wise)."""
     tg = targets.reshape(-1).contiguous()
+    if rows is not None:
+        # x comes from a ragged stack: only its first rows[0] rows exist, the dead rows are gone already
+        M, V = tg.numel(), dec.fc2.weight.shape[0]
+        dlogits = torch.empty((M, V), device=x.device, dtype=torch.float32)
+        ops.gemm_raw(x, dec.fc2.weight, dlogits, M, V, x.shape[1], x.stride(0), dec.fc2.weight.stride(0),
+                     bias_j=dec.fc2.bias, rows_dev=rows)
+        sums, _ = ops.softmax_nll_grad_(dlogits, tg, ignore_index, rows_dev=rows)
+        loss, _ = ops.loss_finish(sums)
+        return loss, ("rows", dlogits, rows)
     if materialize and skip_ignored:
         M = tg.numel()
         order, slot, tg_c, count = ops.compact_targets(tg, ignore_index)
@@ -199,6 +241,9 @@ def vocab_loss(dec, x, targets, ignore_index=0, materialize=True, skip_ignored=T
 
 def vocab_loss_bwd(dec, x, saved, grads):
     """d(loss)/dx and the fc2 gradients from what ``vocab_loss`` saved."""
+    if saved[0] == "rows":
+        _, dlogits, rows = saved
+        return _lin_bwd(grads, "fc2", dec.fc2, dlogits, x, rows=rows)
     if saved[0] == "compact":
         _, dlogits, xc, slot, count = saved
         M, E = xc.shape

@@ -34,8 +34,9 @@ def _row_stride(t, name):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
-def gemm_groups(groups, K, relu=False, extra_flags=0):
-    """groups: list of dicts with P,Q,C (2-D, row-contiguous) and optional bias_j,bias_i,scale_j,shift_j,R."""
+def gemm_groups(groups, K, relu=False, extra_flags=0, rows_dev=None):
+    """groups: list of dicts with P,Q,C (2-D, row-contiguous) and optional bias_j,bias_i,scale_j,shift_j,R.
+    rows_dev: int32 device scalar; only the first rows_dev[0] output rows are computed."""
     lib = _lib.load()
     n = len(groups)
     arr = (GemmGroup * n)()
@@ -62,10 +63,16 @@ def gemm_groups(groups, K, relu=False, extra_flags=0):
             if R.shape != C.shape:
                 raise RuntimeError("capdec gemm: residual shape mismatch")
             g.R, g.ldri, g.ldrj = R.data_ptr(), _row_stride(R, "R"), 1
-    _lib.check(lib.capdec_gemm(arr, n, K, (_lib.GEMM_RELU if relu else 0) | extra_flags, _stream()), "capdec_gemm")
+    flags = (_lib.GEMM_RELU if relu else 0) | extra_flags
+    if rows_dev is None:
+        _lib.check(lib.capdec_gemm(arr, n, K, flags, _stream()), "capdec_gemm")
+        return
+    ex = _lib.GemmExtra()
+    ex.rows_dev = _chk(rows_dev, torch.int32, "rows_dev").data_ptr()
+    _lib.check(lib.capdec_gemm_ex(arr, n, K, flags, byref(ex), _stream()), "capdec_gemm_ex")
 
 
-def linear(x, W, b=None, relu=False, residual=None, scale=None, shift=None, out=None, split_k=False):
+def linear(x, W, b=None, relu=False, residual=None, scale=None, shift=None, out=None, split_k=False, rows_dev=None):
     """y = x W^T + b with fused epilogue; x [M,K] (row stride free), W [N,K].
     split_k: split the contraction over workgroups and add the partial sums with float atomics (long K, few
     output tiles: the 86436-wide YOLO head).  ``out`` must then hold zeros; no relu / residual."""
@@ -76,7 +83,7 @@ def linear(x, W, b=None, relu=False, residual=None, scale=None, shift=None, out=
     if out is None:
         out = (torch.zeros if split_k else torch.empty)((M, N), device=x.device, dtype=torch.float32)
     gemm_groups([dict(P=x, Q=W, C=out, bias_j=b, R=residual, scale_j=scale, shift_j=shift)], K, relu,
-                extra_flags=_lib.GEMM_ATOMIC if split_k else 0)
+                extra_flags=_lib.GEMM_ATOMIC if split_k else 0, rows_dev=rows_dev)
     return out
 
 
@@ -298,12 +305,13 @@ def gemm_raw(P, Q, C, I, J, K, ldp, ldq, flags=0, bias_j=None, R=None, mask=None
     return C
 
 
-def linear_dgrad(dy, W, mask=None, accum=None):
+def linear_dgrad(dy, W, mask=None, accum=None, rows_dev=None):
     """dX = dY W  (dY [M,N], W [N,K]); zeroed where mask <= 0; added onto ``accum`` in place when given."""
     M, N = dy.shape
     K = W.shape[1]
     out = accum if accum is not None else torch.empty((M, K), device=dy.device, dtype=torch.float32)
-    return gemm_raw(dy, W, out, M, K, N, _row_stride(dy, "dy"), _row_stride(W, "W"), _lib.GEMM_TQ, R=accum, mask=mask)
+    return gemm_raw(dy, W, out, M, K, N, _row_stride(dy, "dy"), _row_stride(W, "W"), _lib.GEMM_TQ, R=accum, mask=mask,
+                    rows_dev=rows_dev)
 
 
 def linear_wgrad(dy, x, out=None, rows_dev=None):
@@ -366,12 +374,16 @@ def dropout(x, p, seed, out=None):
     return out
 
 
-def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5, x_div=1):
+def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5, x_div=1, x_map=None, rows_dev=None):
     """s = add + dropout(x); y = LN(s).  Returns (y, s, mean, rstd).  With x_div > 1, x holds one row per
-    ``x_div`` consecutive rows of ``add`` (a per-sample row broadcast over its positions)."""
+    ``x_div`` consecutive rows of ``add`` (a per-sample row broadcast over its positions); with x_map (int32 [M]) row r
+    takes x[x_map[r]].  rows_dev: int32 device scalar, only the first rows_dev[0] rows are processed."""
     lib = _lib.load()
     M, E = add.shape
-    if x.shape != ((M + x_div - 1) // x_div, E) or M % x_div:
+    if x_map is not None:
+        if x_map.numel() != M or x.shape[1] != E:
+            raise RuntimeError("capdec add_layernorm_train: x_map must name one row of x per row of add")
+    elif x.shape != ((M + x_div - 1) // x_div, E) or M % x_div:
         raise RuntimeError(f"capdec add_layernorm_train: x {tuple(x.shape)} does not match add {tuple(add.shape)} / {x_div}")
     y = torch.empty((M, E), device=x.device, dtype=torch.float32)
     s = torch.empty_like(y)
@@ -379,14 +391,16 @@ def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5, x_div=1):
     rstd = torch.empty_like(mean)
     if not x.is_contiguous() or not add.is_contiguous():
         raise RuntimeError("capdec add_layernorm_train: operands must be contiguous")
-    _lib.check(lib.capdec_add_layernorm_train(_chk(x).data_ptr(), x_div, _chk(add).data_ptr(), _chk(gamma).data_ptr(),
-                                              _chk(beta).data_ptr(), eps, M, E, p, seed, y.data_ptr(), s.data_ptr(),
-                                              mean.data_ptr(), rstd.data_ptr(), _stream()),
-               "capdec_add_layernorm_train")
+    _lib.check(lib.capdec_add_layernorm_train_rows(_chk(x).data_ptr(), x_div,
+                                                   None if x_map is None else _chk(x_map, torch.int32, "x_map").data_ptr(),
+                                                   _chk(add).data_ptr(), _chk(gamma).data_ptr(), _chk(beta).data_ptr(),
+                                                   eps, M, E, p, seed, y.data_ptr(), s.data_ptr(), mean.data_ptr(),
+                                                   rstd.data_ptr(), _ptr(rows_dev), _stream()),
+               "capdec_add_layernorm_train_rows")
     return y, s, mean, rstd
 
 
-def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None):
+def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None, rows_dev=None):
     """Returns (d_add, d_x); dgamma/dbeta are accumulated, and so are the column sums of d_x into ``dxsum`` [E]
     when given (the bias gradient of the linear layer whose output was normalised)."""
     lib = _lib.load()
@@ -395,10 +409,10 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None):
         raise RuntimeError("capdec layernorm_bwd: dy must be contiguous")
     d_add = torch.empty((M, E), device=dy.device, dtype=torch.float32)
     d_x = torch.empty_like(d_add) if p > 0 else None
-    _lib.check(lib.capdec_layernorm_bwd(_chk(dy).data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                        _chk(gamma).data_ptr(), M, E, p, seed, d_add.data_ptr(), _ptr(d_x),
-                                        _chk(dgamma).data_ptr(), _chk(dbeta).data_ptr(), _ptr(dxsum), _stream()),
-               "capdec_layernorm_bwd")
+    _lib.check(lib.capdec_layernorm_bwd_rows(_chk(dy).data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             _chk(gamma).data_ptr(), M, E, p, seed, d_add.data_ptr(), _ptr(d_x),
+                                             _chk(dgamma).data_ptr(), _chk(dbeta).data_ptr(), _ptr(dxsum),
+                                             _ptr(rows_dev), _stream()), "capdec_layernorm_bwd_rows")
     return d_add, (d_x if p > 0 else d_add)
 
 
@@ -430,12 +444,12 @@ def attention_bwd(q, k, v, dout, lse, B, H, Tq, Tk, causal=False, ids32=None, dq
     return dq, dk, dv
 
 
-def embed_bwd(ids, dx, demb):
+def embed_bwd(ids, dx, demb, rows_dev=None):
     lib = _lib.load()
     ids = ids.contiguous()
     rows, E = dx.shape
-    _lib.check(lib.capdec_embed_bwd(_chk(ids, torch.int64).data_ptr(), _chk(dx).data_ptr(), rows, E, demb.shape[0],
-                                    _chk(demb).data_ptr(), _stream()), "capdec_embed_bwd")
+    _lib.check(lib.capdec_embed_bwd_rows(_chk(ids, torch.int64).data_ptr(), _chk(dx).data_ptr(), rows, E, demb.shape[0],
+                                         _chk(demb).data_ptr(), _ptr(rows_dev), _stream()), "capdec_embed_bwd_rows")
     return demb
 
 
@@ -457,6 +471,70 @@ def softmax_grad_logits(x, W, b, lse, targets, gscale, ignore_index=0, out=None)
         out = torch.empty((M, V), device=x.device, dtype=torch.float32)
     return gemm_raw(x, W, out, M, V, K, _row_stride(x, "x"), _row_stride(W, "W"), 0, bias_j=b, lse=lse, tgt=targets,
                     gscale=gscale, ignore_index=ignore_index)
+
+
+def group_sum_segments(x, seg_off, G):
+    """[rows, E] -> [G, E]: out[g] = sum of the rows [seg_off[g], seg_off[g+1]) (seg_off: int32 [G+1] on the device)."""
+    lib = _lib.load()
+    E = x.shape[1]
+    out = torch.empty((G, E), device=x.device, dtype=torch.float32)
+    _lib.check(lib.capdec_group_sum_segments(_chk(x).data_ptr(), G, _chk(seg_off, torch.int32, "seg_off").data_ptr(), E,
+                                             out.data_ptr(), _stream()), "capdec_group_sum_segments")
+    return out
+
+
+class RaggedRows:
+    """The live prefixes of a padded caption batch as a ragged batch (see capdec_compact_prefix)."""
+
+    def __init__(self, ids, targets, pad=0):
+        lib = _lib.load()
+        _chk(ids, torch.int64, "ids")
+        _chk(targets, torch.int64, "targets")
+        if ids.shape != targets.shape or ids.dim() != 2 or not ids.is_contiguous() or not targets.is_contiguous():
+            raise RuntimeError("capdec RaggedRows: ids and targets must be contiguous [B,T] tensors")
+        B, T = ids.shape
+        M, dev = B * T, ids.device
+        self.B, self.T, self.M = B, T, M
+        self.order = torch.empty(M, device=dev, dtype=torch.int64)       # dense row of slot s
+        self.slot = torch.empty(M, device=dev, dtype=torch.int64)        # slot of dense row r (M: dead)
+        self.seq_off = torch.empty(B + 1, device=dev, dtype=torch.int32)
+        self.sample = torch.empty(M, device=dev, dtype=torch.int32)
+        self.ids_c = torch.empty(M, device=dev, dtype=torch.int32)
+        self.targets_c = torch.empty(M, device=dev, dtype=torch.int64)
+        self.counts = torch.empty(2, device=dev, dtype=torch.int32)
+        _lib.check(lib.capdec_compact_prefix(ids.data_ptr(), targets.data_ptr(), B, T, pad, self.order.data_ptr(),
+                                             self.slot.data_ptr(), self.seq_off.data_ptr(), self.sample.data_ptr(),
+                                             self.ids_c.data_ptr(), self.targets_c.data_ptr(), self.counts.data_ptr(),
+                                             _stream()), "capdec_compact_prefix")
+        self.rows = self.counts[:1]      # live rows rounded up to a multiple of 32: the row limit of every kernel
+
+
+def attention_ragged(q, k, v, rr, H, want_lse=False):
+    """Causal self-attention over a ragged batch ``rr`` (RaggedRows); q, k, v [M,E] by slot.  The output rows outside
+    every sample are zero."""
+    lib = _lib.load()
+    M, E = q.shape
+    out = torch.zeros((M, E), device=q.device, dtype=torch.float32)
+    lse = torch.empty((rr.B, H, rr.T), device=q.device, dtype=torch.float32) if want_lse else None
+    _lib.check(lib.capdec_attention_ragged(_chk(q).data_ptr(), _row_stride(q, "q"), _chk(k).data_ptr(), _row_stride(k, "k"),
+                                           _chk(v).data_ptr(), _row_stride(v, "v"), out.data_ptr(), E, rr.B, H, rr.T,
+                                           E // H, rr.ids_c.data_ptr(), rr.seq_off.data_ptr(), _ptr(lse), _stream()),
+               "capdec_attention_ragged")
+    return (out, lse) if want_lse else out
+
+
+def attention_bwd_ragged(q, k, v, dout, lse, rr, H):
+    """Backward of ``attention_ragged``.  Returns (dq, dk, dv) [M,E]; rows outside every sample are zero."""
+    lib = _lib.load()
+    M, E = q.shape
+    d = torch.zeros((3, M, E), device=q.device, dtype=torch.float32)
+    _lib.check(lib.capdec_attention_bwd_ragged(_chk(q).data_ptr(), _row_stride(q, "q"), _chk(k).data_ptr(),
+                                               _row_stride(k, "k"), _chk(v).data_ptr(), _row_stride(v, "v"),
+                                               _chk(dout).data_ptr(), _row_stride(dout, "dout"), _chk(lse).data_ptr(),
+                                               d[0].data_ptr(), E, d[1].data_ptr(), E, d[2].data_ptr(), E, rr.B, H, rr.T,
+                                               E // H, rr.ids_c.data_ptr(), rr.seq_off.data_ptr(), _stream()),
+               "capdec_attention_bwd_ragged")
+    return d[0], d[1], d[2]
 
 
 def softmax_nll_grad_(logits, targets, ignore_index=0, rows_dev=None):

@@ -32,11 +32,16 @@ def _head_spec(model):
 class CaptionTrainer:
     """One object per process (one process per GPU)."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, pad_idx=0, overlap=True):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, pad_idx=0, overlap=True,
+                 skip_dead_rows=True):
         """overlap=True: one async all-reduce per gradient segment, issued as soon as the backward pass has enqueued
-        that segment; overlap=False: a single all-reduce of the whole flat gradient buffer after the backward pass."""
+        that segment; overlap=False: a single all-reduce of the whole flat gradient buffer after the backward pass.
+        skip_dead_rows: run the Transformer stack on the live prefix of every caption only (the positions from a
+        caption's last counted target on feed nothing but ignored loss terms); same loss and gradients, the dropout
+        masks are drawn per live row.  Applies where ``autograd.ragged_supported`` holds, else the full rows run."""
         self.model = model
         self.overlap = overlap
+        self.skip_dead_rows = skip_dead_rows
         self.lr, self.betas, self.eps, self.pad_idx = lr, betas, eps, pad_idx
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -176,8 +181,14 @@ class CaptionTrainer:
         y, htape = AG.head_forward(model, parts, feats, False, AG.draw_seed() if p > 0 else 0)
         B = feats.shape[0]
         enc = y.view(B, len(parts), -1)
-        x, tape = AG.tf_forward(model, enc, ids, p, AG.draw_seed() if p > 0 else 0)
-        loss, saved = AG.vocab_loss(model, x, tgt, self.pad_idx)
+        rg = None
+        if self.skip_dead_rows and AG.ragged_supported(model, enc.shape[1], ids.shape[1]):
+            rg = ops.RaggedRows(ids, tgt, self.pad_idx)
+        x, tape = AG.tf_forward(model, enc, ids, p, AG.draw_seed() if p > 0 else 0, ragged=rg)
+        if rg is not None:
+            loss, saved = AG.vocab_loss(model, x, rg.targets_c, self.pad_idx, rows=rg.rows)
+        else:
+            loss, saved = AG.vocab_loss(model, x, tgt, self.pad_idx)
         # ---- backward, gradient exchange overlapped segment by segment ----
         works = []
         dx = AG.vocab_loss_bwd(model, x, saved, self.grads)

@@ -157,6 +157,8 @@ struct AttnArgs {
     // row-list form (decode steps): Tq == 1, query/output row r, sample and position from row_map[r]
     const int32_t* row_map; int map_div;     // b = row_map[r] / map_div, position = row_map[r] % map_div
     const int32_t* rows_dev;                 // nullable device scalar: only rows r < rows_dev[0] are live
+    // ragged self-attention (short kernel only): sample b is the rows [seq_off[b], seq_off[b+1]) of q, k, v, out and ids
+    const int32_t* seq_off;
 };
 
 template <int NM>
@@ -263,27 +265,37 @@ template <int NM>
 __global__ __launch_bounds__(256) void attention_short_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int dk = a.dk, LD = dk + 16, Tq = a.Tq, Tk = a.Tk;
+    const int dk = a.dk, LD = dk + 16;
     float* Ks = lds;
-    float* Vs = Ks + Tk * LD;
-    float* scs = Vs + Tk * LD;             // [4][Tk] score rows
+    float* Vs = Ks + a.Tk * LD;
+    float* scs = Vs + a.Tk * LD;           // [4][Tk] score rows
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
     const int nv = dk / 4;
+    int Tq = a.Tq, Tk = a.Tk;
+    int64_t q0 = (int64_t)b * Tq, id0 = (int64_t)b * a.ldid;
+    const float* kb = a.k + (int64_t)b * a.sk;
+    const float* vb = a.v + (int64_t)b * a.sv;
+    if (a.seq_off) {
+        q0 = id0 = a.seq_off[b];
+        Tq = Tk = min(a.Tk, a.seq_off[b + 1] - a.seq_off[b]);
+        kb = a.k + q0 * a.ldk;
+        vb = a.v + q0 * a.ldv;
+    }
     for (int idx = threadIdx.x; idx < Tk * nv; idx += 256) {
         const int r = idx / nv, c = idx - r * nv;
         *reinterpret_cast<f32x4*>(&Ks[r * LD + 4 * c]) =
-            *reinterpret_cast<const f32x4*>(a.k + (int64_t)b * a.sk + (int64_t)r * a.ldk + (int64_t)h * dk + 4 * c);
+            *reinterpret_cast<const f32x4*>(kb + (int64_t)r * a.ldk + (int64_t)h * dk + 4 * c);
         *reinterpret_cast<f32x4*>(&Vs[r * LD + 4 * c]) =
-            *reinterpret_cast<const f32x4*>(a.v + (int64_t)b * a.sv + (int64_t)r * a.ldv + (int64_t)h * dk + 4 * c);
+            *reinterpret_cast<const f32x4*>(vb + (int64_t)r * a.ldv + (int64_t)h * dk + 4 * c);
     }
     __syncthreads();
-    float* sc = scs + wave * Tk;
+    float* sc = scs + wave * a.Tk;
     const float scale = sqrtf((float)dk);
     const int part = lane & 3, kl = lane >> 2;
     const int lpv = dk / 4, grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
     for (int i = wave; i < Tq; i += 4) {
-        const int64_t qrow = (int64_t)b * Tq + i;
-        const bool pad_row = a.ids && a.ids[(int64_t)b * a.ldid + i] == 0;
+        const int64_t qrow = q0 + i;
+        const bool pad_row = a.ids && a.ids[id0 + i] == 0;
         int nkeys = Tk;
         if (a.causal && !pad_row) {
             nkeys = i + a.causal_off + 1;
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(256) void attention_short_kernel(AttnArgs a) {
             acc[3] += __shfl_xor(acc[3], o, 64);
         }
         if (grp == 0) *reinterpret_cast<f32x4*>(a.out + qrow * a.ldo + (int64_t)h * dk + 4 * dl) = acc;
-        if (lane == 0 && a.lse) a.lse[((int64_t)b * a.H + h) * Tq + i] = mx + logf(sum);
+        if (lane == 0 && a.lse) a.lse[((int64_t)b * a.H + h) * a.Tq + i] = mx + logf(sum);
     }
 }
 
@@ -527,6 +539,26 @@ int capdec_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, i
 #define CAPDEC_CALL(NM_)                                                                                          \
     hipLaunchKernelGGL(attention_kernel<NM_>, dim3((unsigned)((total + 3) / 4)), dim3(256), 4 * Tk * sizeof(float), \
                        (hipStream_t)stream, a)
+    CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
+#undef CAPDEC_CALL
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            float* out, int64_t ldo, int B, int H, int T, int dk, const int32_t* ids,
+                            const int32_t* seq_off, float* lse, void* stream) {
+    CAPDEC_REQUIRE(q && k && v && out && seq_off && B >= 0 && H >= 1 && T >= 1 && T <= 64);
+    CAPDEC_REQUIRE(dk == 16 || dk == 32 || dk == 64 || dk == 128 || dk == 256);
+    if (!capdec_aligned16(q) || !capdec_aligned16(k) || !capdec_aligned16(v) || !capdec_aligned16(out) || ldq % 4 ||
+        ldk % 4 || ldv % 4 || ldo % 4)
+        return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    const size_t short_lds = ((size_t)2 * T * (dk + 16) + 4 * (size_t)T) * sizeof(float);
+    CAPDEC_REQUIRE(short_lds <= 64 * 1024);
+    AttnArgs a{q, ldq, k, ldk, 0, v, ldv, 0, out, ldo, B, H, T, T, dk, 1, 0, ids, 0, lse, nullptr, 1, nullptr, seq_off};
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attention_short_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), short_lds, (hipStream_t)stream, a)
     CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();

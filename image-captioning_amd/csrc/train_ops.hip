@@ -3,6 +3,7 @@
 // All are HBM-bound: one 64-lane wavefront per row, 16-byte accesses, shuffle reductions; cross-row
 // reductions (dgamma/dbeta/bias gradients) accumulate per workgroup and finish with float atomics.
 #include "common.h"
+#include <limits.h>
 #include <math.h>
 
 namespace {
@@ -72,12 +73,14 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
                                                            const float* __restrict__ beta, float eps, int M, int E,
                                                            int x_div, float p, uint64_t seed, float* __restrict__ y,
                                                            float* __restrict__ s_out, float* __restrict__ mean_out,
-                                                           float* __restrict__ rstd_out) {
+                                                           float* __restrict__ rstd_out,
+                                                           const int32_t* __restrict__ x_map,
+                                                           const int32_t* __restrict__ rows_dev) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= M) return;
+    if (row >= M || (rows_dev && row >= rows_dev[0])) return;
     const int nv = E / 4;
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)(row / x_div) * E);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)(x_map ? x_map[row] : row / x_div) * E);
     const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (int64_t)row * E) : nullptr;
     const float inv_keep = 1.0f / (1.0f - p);
     f32x4 v[NV];
@@ -139,9 +142,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, int M, int E, float p,
                                                      uint64_t seed, float* __restrict__ d_add, float* __restrict__ d_x,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     float* __restrict__ dxsum) {
+                                                     float* __restrict__ dxsum, const int32_t* __restrict__ rows_dev) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][3][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (rows_dev) M = min(M, rows_dev[0]);
+    if ((int)blockIdx.x * LNB_ROWS >= M) return;
     const int nv = E / 4;
     const float inv_keep = 1.0f / (1.0f - p);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
@@ -273,14 +278,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 
 // ---- sums of consecutive row groups: out[g, :] = sum_{t<T} x[g*T + t, :]  (gradient of a row broadcast) ----
 __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ x, int G, int T, int E,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const int32_t* __restrict__ seg_off) {
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (g >= G) return;
     const int nv = E / 4;
+    // seg_off: group g is the rows [seg_off[g], seg_off[g+1]) instead of [g*T, (g+1)*T)
+    const int64_t r0 = seg_off ? seg_off[g] : (int64_t)g * T;
+    if (seg_off) T = seg_off[g + 1] - seg_off[g];
     for (int c = lane; c < nv; c += 64) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < T; ++t) acc += reinterpret_cast<const f32x4*>(x + ((int64_t)g * T + t) * E)[c];
+        for (int t = 0; t < T; ++t) acc += reinterpret_cast<const f32x4*>(x + (r0 + t) * E)[c];
         reinterpret_cast<f32x4*>(out + (int64_t)g * E)[c] = acc;
     }
 }
@@ -293,10 +301,13 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict_
 constexpr int EB_HOT = 4, EB_ROWS = 64;
 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
-                                                        int rows, int E, int V, float* __restrict__ demb) {
+                                                        int rows, int E, int V, float* __restrict__ demb,
+                                                        const int32_t* __restrict__ rows_dev) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [EB_HOT][E]
     __shared__ int used[EB_HOT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (rows_dev) rows = min(rows, rows_dev[0]);
+    if ((int)blockIdx.x * EB_ROWS >= rows) return;
     for (int c = threadIdx.x; c < EB_HOT * E; c += 256) lds[c] = 0.f;
     if (threadIdx.x < EB_HOT) used[threadIdx.x] = 0;
     __syncthreads();
@@ -385,6 +396,8 @@ struct AttnBwdArgs {
     int B, H, Tq, Tk, dk_;
     int causal, causal_off;
     const int32_t* ids; int64_t ldid;
+    // ragged self-attention (fused kernel only): sample b is the rows [seq_off[b], seq_off[b+1]) of every operand and ids
+    const int32_t* seq_off;
 };
 
 template <int NM>
@@ -550,18 +563,32 @@ template <int NM>
 __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int dk = a.dk_, LD = dk + 16, Tq = a.Tq, Tk = a.Tk;
+    const int dk = a.dk_, LD = dk + 16;
     float* Qs = lds;
-    float* Os = Qs + Tq * LD;
-    float* Ks = Os + Tq * LD;
-    float* Vs = Ks + Tk * LD;
-    float* Ps = Vs + Tk * LD;          // [Tq][Tk] softmax probabilities
-    float* Ds = Ps + Tq * Tk;          // [Tq][Tk] dS = P * (dP - D)
+    float* Os = Qs + a.Tq * LD;
+    float* Ks = Os + a.Tq * LD;
+    float* Vs = Ks + a.Tk * LD;
+    float* Ps = Vs + a.Tk * LD;        // [Tq][Tk] softmax probabilities
+    float* Ds = Ps + a.Tq * a.Tk;      // [Tq][Tk] dS = P * (dP - D)
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
     const int nv = dk / 4;
+    int Tq = a.Tq, Tk = a.Tk;
+    int64_t q0 = (int64_t)b * Tq, id0 = (int64_t)b * a.ldid;
+    const float* kb = a.k + (int64_t)b * a.sk;
+    const float* vb = a.v + (int64_t)b * a.sv;
+    float* dkb = a.dk + (int64_t)b * a.sdk;
+    float* dvb = a.dv + (int64_t)b * a.sdv;
+    if (a.seq_off) {
+        q0 = id0 = a.seq_off[b];
+        Tq = Tk = min(a.Tk, a.seq_off[b + 1] - a.seq_off[b]);
+        kb = a.k + q0 * a.ldk;
+        vb = a.v + q0 * a.ldv;
+        dkb = a.dk + q0 * a.lddk;
+        dvb = a.dv + q0 * a.lddv;
+    }
     for (int idx = threadIdx.x; idx < Tq * nv; idx += 256) {
         const int r = idx / nv, c = idx - r * nv;
-        const int64_t row = (int64_t)b * Tq + r;
+        const int64_t row = q0 + r;
         *reinterpret_cast<f32x4*>(&Qs[r * LD + 4 * c]) =
             *reinterpret_cast<const f32x4*>(a.q + row * a.ldq + (int64_t)h * dk + 4 * c);
         *reinterpret_cast<f32x4*>(&Os[r * LD + 4 * c]) =
@@ -570,9 +597,9 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
     for (int idx = threadIdx.x; idx < Tk * nv; idx += 256) {
         const int r = idx / nv, c = idx - r * nv;
         *reinterpret_cast<f32x4*>(&Ks[r * LD + 4 * c]) =
-            *reinterpret_cast<const f32x4*>(a.k + (int64_t)b * a.sk + (int64_t)r * a.ldk + (int64_t)h * dk + 4 * c);
+            *reinterpret_cast<const f32x4*>(kb + (int64_t)r * a.ldk + (int64_t)h * dk + 4 * c);
         *reinterpret_cast<f32x4*>(&Vs[r * LD + 4 * c]) =
-            *reinterpret_cast<const f32x4*>(a.v + (int64_t)b * a.sv + (int64_t)r * a.ldv + (int64_t)h * dk + 4 * c);
+            *reinterpret_cast<const f32x4*>(vb + (int64_t)r * a.ldv + (int64_t)h * dk + 4 * c);
     }
     __syncthreads();
     const float scale = sqrtf((float)dk);
@@ -580,14 +607,14 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
     const int lpv = dk / 4, grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
     // query rows: P, dS and dq
     for (int i = wave; i < Tq; i += 4) {
-        const bool pad_row = a.ids && a.ids[(int64_t)b * a.ldid + i] == 0;
+        const bool pad_row = a.ids && a.ids[id0 + i] == 0;
         int nkeys = Tk;
         if (a.causal && !pad_row) {
             nkeys = i + a.causal_off + 1;
             nkeys = nkeys < 1 ? 1 : (nkeys > Tk ? Tk : nkeys);
         }
-        float* pi = Ps + i * Tk;
-        float* di = Ds + i * Tk;
+        float* pi = Ps + i * a.Tk;
+        float* di = Ds + i * a.Tk;
         if (pad_row) {
             // uniform softmax over all keys, independent of q and k: dS = 0
             for (int j = lane; j < Tk; j += 64) {
@@ -598,7 +625,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
             f32x4 qreg[NM], oreg[NM];
             load_parts(qreg, Qs + i * LD + 4 * part);
             load_parts(oreg, Os + i * LD + 4 * part);
-            const float l = a.lse[((int64_t)b * a.H + h) * Tq + i];
+            const float l = a.lse[((int64_t)b * a.H + h) * a.Tq + i];
             float dacc = 0.f;
             for (int j0 = 0; j0 < nkeys; j0 += 16) {
                 const int j = j0 + kl;
@@ -632,22 +659,22 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
                 acc += *reinterpret_cast<const f32x4*>(Ks + j * LD + 4 * dl) * (di[j] / scale);
         group_reduce(acc, lpv);
         if (grp == 0)
-            *reinterpret_cast<f32x4*>(a.dq + ((int64_t)b * Tq + i) * a.lddq + (int64_t)h * dk + 4 * dl) = acc;
+            *reinterpret_cast<f32x4*>(a.dq + (q0 + i) * a.lddq + (int64_t)h * dk + 4 * dl) = acc;
     }
     __syncthreads();
     // keys: dk_j = sum_i dS_ij q_i / sqrt(dk), dv_j = sum_i P_ij dO_i
     for (int j = wave; j < Tk; j += 4) {
         f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
         for (int i = grp; i < Tq; i += ngrp) {
-            const float pr = Ps[i * Tk + j], d = Ds[i * Tk + j];
+            const float pr = Ps[i * a.Tk + j], d = Ds[i * a.Tk + j];
             av += *reinterpret_cast<const f32x4*>(Os + i * LD + 4 * dl) * pr;
             ak += *reinterpret_cast<const f32x4*>(Qs + i * LD + 4 * dl) * (d / scale);
         }
         group_reduce(ak, lpv);
         group_reduce(av, lpv);
         if (grp == 0) {
-            *reinterpret_cast<f32x4*>(a.dk + (int64_t)b * a.sdk + (int64_t)j * a.lddk + (int64_t)h * dk + 4 * dl) = ak;
-            *reinterpret_cast<f32x4*>(a.dv + (int64_t)b * a.sdv + (int64_t)j * a.lddv + (int64_t)h * dk + 4 * dl) = av;
+            *reinterpret_cast<f32x4*>(dkb + (int64_t)j * a.lddk + (int64_t)h * dk + 4 * dl) = ak;
+            *reinterpret_cast<f32x4*>(dvb + (int64_t)j * a.lddv + (int64_t)h * dk + 4 * dl) = av;
         }
     }
 }
@@ -936,6 +963,76 @@ __global__ __launch_bounds__(1024) void compact_targets_kernel(const int64_t* __
     if (t == 0) count[0] = total;
 }
 
+
+// ---- live prefixes of a padded caption batch ---------------------------------------------------------------------
+// Sample b's rows from its last counted target on are dead: they feed nothing but ignored loss terms (causal
+// self-attention: a row only sees earlier rows).  len[b] = 1 + last position with a counted target, or T when an
+// input id inside that prefix is <PAD> (the reference lets such a query row attend uniformly over all T keys,
+// transformer.py:18-22, so the sample keeps its full length).  Slots are assigned sample by sample, so each sample's
+// live rows stay contiguous and ordered: a ragged batch.  One workgroup; thread t owns samples t, t+1024, ...
+__global__ __launch_bounds__(1024) void compact_prefix_kernel(const int64_t* __restrict__ ids,
+                                                              const int64_t* __restrict__ targets, int B, int T,
+                                                              int64_t pad, int64_t* __restrict__ order,
+                                                              int64_t* __restrict__ slot, int32_t* __restrict__ seq_off,
+                                                              int32_t* __restrict__ sample, int32_t* __restrict__ ids_c,
+                                                              int64_t* __restrict__ tgt_c, int32_t* __restrict__ count) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int lo = min(B, t * per), hi = min(B, lo + per);
+    const int M = B * T;
+    auto length = [&](int b) {
+        int len = 0;
+        for (int p = T - 1; p >= 0; --p)
+            if (targets[(int64_t)b * T + p] != pad) { len = p + 1; break; }
+        for (int p = 0; p < len; ++p)
+            if (ids[(int64_t)b * T + p] == pad) return T;
+        return len;
+    };
+    int n = 0;
+    for (int b = lo; b < hi; ++b) n += length(b);
+    part[t] = n;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {          // inclusive scan
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const int total = part[1023];
+    const int total32 = min(M, (total + 31) / 32 * 32);
+    int at = part[t] - n;
+    for (int b = lo; b < hi; ++b) {
+        const int len = length(b);
+        seq_off[b] = at;
+        for (int p = 0; p < T; ++p) {
+            const int64_t r = (int64_t)b * T + p;
+            if (p < len) {
+                order[at] = r;
+                sample[at] = b;
+                ids_c[at] = (int32_t)ids[r];
+                tgt_c[at] = targets[r];
+                slot[r] = at++;
+            } else {
+                slot[r] = M;                      // the caller's all-zero extra row
+            }
+        }
+    }
+    if (t == 0) seq_off[B] = total;
+    // slots that belong to no sample: copies of row 0 with an ignored target.  Those below the next multiple of
+    // 32 are computed like live rows (contractions over the rows read whole k-tiles); their gradients are zero.
+    for (int r = total + t; r < M; r += 1024) {
+        order[r] = 0;
+        sample[r] = 0;
+        ids_c[r] = (int32_t)ids[0];
+        tgt_c[r] = pad;
+    }
+    if (t == 0) {
+        count[0] = total32;
+        count[1] = total;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -955,6 +1052,13 @@ int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, 
 int capdec_add_layernorm_train(const float* x, int x_div, const float* add, const float* gamma, const float* beta,
                                float eps, int M, int E, float p, uint64_t seed, float* y, float* s_out, float* mean,
                                float* rstd, void* stream) {
+    return capdec_add_layernorm_train_rows(x, x_div, nullptr, add, gamma, beta, eps, M, E, p, seed, y, s_out, mean, rstd,
+                                           nullptr, stream);
+}
+
+int capdec_add_layernorm_train_rows(const float* x, int x_div, const int32_t* x_map, const float* add, const float* gamma,
+                                    const float* beta, float eps, int M, int E, float p, uint64_t seed, float* y,
+                                    float* s_out, float* mean, float* rstd, const int32_t* rows_dev, void* stream) {
     CAPDEC_REQUIRE(x && gamma && beta && y && M >= 0 && E >= 4 && E % 4 == 0 && E <= 256 * LN_MAXV && p >= 0.f && p < 1.f);
     CAPDEC_REQUIRE(x_div >= 1);
     if (!capdec_aligned16(x) || !capdec_aligned16(y) || !capdec_aligned16(gamma) || !capdec_aligned16(beta) ||
@@ -963,7 +1067,7 @@ int capdec_add_layernorm_train(const float* x, int x_div, const float* add, cons
     if (M == 0) return 0;
 #define CAPDEC_CALL(NV_)                                                                                          \
     hipLaunchKernelGGL(ln_train_fwd_kernel<NV_>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, gamma, \
-                       beta, eps, M, E, x_div, p, seed, y, s_out, mean, rstd)
+                       beta, eps, M, E, x_div, p, seed, y, s_out, mean, rstd, x_map, rows_dev)
     CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
@@ -973,6 +1077,13 @@ int capdec_add_layernorm_train(const float* x, int x_div, const float* add, cons
 int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                          int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma, float* dbeta,
                          float* dxsum, void* stream) {
+    return capdec_layernorm_bwd_rows(dy, s, mean, rstd, gamma, M, E, p, seed, d_add, d_x, dgamma, dbeta, dxsum, nullptr,
+                                     stream);
+}
+
+int capdec_layernorm_bwd_rows(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
+                              int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma,
+                              float* dbeta, float* dxsum, const int32_t* rows_dev, void* stream) {
     CAPDEC_REQUIRE(dy && s && mean && rstd && gamma && dgamma && dbeta && M >= 0 && E >= 4 && E % 4 == 0 &&
                    E <= 256 * LN_MAXV && p >= 0.f && p < 1.f);
     if (!capdec_aligned16(dy) || !capdec_aligned16(s) || !capdec_aligned16(gamma) || (d_add && !capdec_aligned16(d_add)) ||
@@ -985,7 +1096,7 @@ int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, con
     if (!wide_ok) return CAPDEC_EINVAL;
 #define CAPDEC_CALL(NV_)                                                                                           \
     hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 12 * E * sizeof(float),    \
-                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, d_add, d_x, dgamma, dbeta, dxsum)
+                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, d_add, d_x, dgamma, dbeta, dxsum, rows_dev)
     CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
@@ -1011,17 +1122,31 @@ int capdec_group_sum(const float* x, int G, int T, int E, float* out, void* stre
     CAPDEC_REQUIRE(x && out && G >= 0 && T >= 1 && E >= 4 && E % 4 == 0);
     if (!capdec_aligned16(x) || !capdec_aligned16(out)) return CAPDEC_EALIGN;
     if (G == 0) return 0;
-    hipLaunchKernelGGL(group_sum_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, G, T, E, out);
+    hipLaunchKernelGGL(group_sum_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, G, T, E, out, nullptr);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_group_sum_segments(const float* x, int G, const int32_t* seg_off, int E, float* out, void* stream) {
+    CAPDEC_REQUIRE(x && out && seg_off && G >= 0 && E >= 4 && E % 4 == 0);
+    if (!capdec_aligned16(x) || !capdec_aligned16(out)) return CAPDEC_EALIGN;
+    if (G == 0) return 0;
+    hipLaunchKernelGGL(group_sum_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, G, 0, E, out, seg_off);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
 
 int capdec_embed_bwd(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb, void* stream) {
+    return capdec_embed_bwd_rows(ids, dx, rows, E, V, demb, nullptr, stream);
+}
+
+int capdec_embed_bwd_rows(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb,
+                          const int32_t* rows_dev, void* stream) {
     CAPDEC_REQUIRE(ids && dx && demb && rows >= 0 && E >= 1 && V >= 1);
     if (rows == 0) return 0;
     CAPDEC_REQUIRE((size_t)EB_HOT * E * sizeof(float) <= 60 * 1024);
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + EB_ROWS - 1) / EB_ROWS), dim3(256), EB_HOT * E * sizeof(float),
-                       (hipStream_t)stream, ids, dx, rows, E, V, demb);
+                       (hipStream_t)stream, ids, dx, rows, E, V, demb, rows_dev);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -1039,6 +1164,39 @@ int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma
 static int g_attn_bwd_two_pass = 0;
 int capdec_attention_bwd_force_two_pass(int on) {
     g_attn_bwd_two_pass = on ? 1 : 0;
+    return 0;
+}
+
+int capdec_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                const float* dout, int64_t ldo, const float* lse, float* dq, int64_t lddq, float* dk,
+                                int64_t lddk, float* dv, int64_t lddv, int B, int H, int T, int dkh, const int32_t* ids,
+                                const int32_t* seq_off, void* stream) {
+    CAPDEC_REQUIRE(q && k && v && dout && lse && dq && dk && dv && seq_off && B >= 0 && H >= 1 && T >= 1 && T <= 64);
+    CAPDEC_REQUIRE(dkh == 16 || dkh == 32 || dkh == 64 || dkh == 128 || dkh == 256);
+    if (!capdec_aligned16(q) || !capdec_aligned16(k) || !capdec_aligned16(v) || !capdec_aligned16(dout) ||
+        !capdec_aligned16(dq) || !capdec_aligned16(dk) || !capdec_aligned16(dv) || ldq % 4 || ldk % 4 || ldv % 4 ||
+        ldo % 4 || lddq % 4 || lddk % 4 || lddv % 4)
+        return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    const size_t fused_lds = ((size_t)4 * T * (dkh + 16) + (size_t)2 * T * T) * sizeof(float);
+    CAPDEC_REQUIRE(fused_lds <= 144 * 1024);
+    AttnBwdArgs a{q, ldq, k, ldk, 0, v, ldv, 0, dout, ldo, nullptr, 0, lse, nullptr, dq, lddq, dk, lddk, 0, dv, lddv, 0,
+                  B, H, T, T, dkh, 1, 0, ids, 0, seq_off};
+    static const bool ready = [] {
+        bool ok = true;
+#define CAPDEC_CALL(NM_)                                                                                    \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NM_>),               \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess
+        CAPDEC_CALL(1); CAPDEC_CALL(2); CAPDEC_CALL(4); CAPDEC_CALL(8); CAPDEC_CALL(16);
+#undef CAPDEC_CALL
+        return ok;
+    }();
+    if (!ready) return CAPDEC_EINVAL;
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), fused_lds, (hipStream_t)stream, a)
+    CAPDEC_DK_DISPATCH(dkh, CAPDEC_CALL);
+#undef CAPDEC_CALL
+    CAPDEC_LAUNCH_CHECK();
     return 0;
 }
 
@@ -1145,6 +1303,17 @@ int capdec_compact_targets(const int64_t* targets, int M, int64_t ignore_index, 
     if (M == 0) return (int)hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream);
     hipLaunchKernelGGL(compact_targets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, targets, M, ignore_index, order,
                        slot, targets_c, count);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_compact_prefix(const int64_t* ids, const int64_t* targets, int B, int T, int64_t pad, int64_t* order,
+                          int64_t* slot, int32_t* seq_off, int32_t* sample, int32_t* ids_c, int64_t* targets_c,
+                          int32_t* count, void* stream) {
+    CAPDEC_REQUIRE(ids && targets && order && slot && seq_off && sample && ids_c && targets_c && count);
+    CAPDEC_REQUIRE(B >= 1 && T >= 1 && (int64_t)B * T < INT_MAX);
+    hipLaunchKernelGGL(compact_prefix_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, targets, B, T, pad, order,
+                       slot, seq_off, sample, ids_c, targets_c, count);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

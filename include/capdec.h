@@ -141,6 +141,12 @@ int capdec_add_layernorm(const float* x, const float* add, int add_div, const fl
 int capdec_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
                      int64_t ldv, int64_t sv, float* out, int64_t ldo, int B, int H, int Tq, int Tk, int dk,
                      int causal, int causal_off, const int32_t* ids, int64_t ldid, float* lse, void* stream);
+/* Causal self-attention over a ragged batch (see capdec_compact_prefix): sample b is the rows [seq_off[b], seq_off[b+1])
+ * of q, k, v, out (row strides ld*) and of ids (nullable; <PAD> query rows as in capdec_attention).  T = the longest
+ * possible sample (<= 64); lse [B,H,T] nullable. */
+int capdec_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            float* out, int64_t ldo, int B, int H, int T, int dk, const int32_t* ids,
+                            const int32_t* seq_off, float* lse, void* stream);
 
 /* BatchNorm1d over [B,C] (cnnattn_model.py:13,29; vitattn_model.py:29,45; vitcnnattn_model.py:33,51;
  * yolocnnattn_model.py:61,79; cnnrnn_model.py:14,24).
@@ -169,19 +175,33 @@ int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, 
 int capdec_add_layernorm_train(const float* x, int x_div, const float* add, const float* gamma, const float* beta,
                                float eps, int M, int E, float p, uint64_t seed, float* y, float* s_out, float* mean,
                                float* rstd, void* stream);
+/* The same with the broadcast row taken from x_map (nullable: x row of output row r is x_map[r] instead of r / x_div)
+ * and only the first rows_dev[0] rows processed (rows_dev: nullable device scalar). */
+int capdec_add_layernorm_train_rows(const float* x, int x_div, const int32_t* x_map, const float* add, const float* gamma,
+                                    const float* beta, float eps, int M, int E, float p, uint64_t seed, float* y,
+                                    float* s_out, float* mean, float* rstd, const int32_t* rows_dev, void* stream);
 /* d_add = dLN/ds ; d_x = d_add * dropout mask (same p, seed as the forward) ; dgamma/dbeta accumulated;
  * dxsum (nullable, [E], accumulated): column sums of d_x = the bias gradient of the linear layer that produced x */
 int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                          int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma, float* dbeta,
                          float* dxsum, void* stream);
+/* The same over the first min(M, rows_dev[0]) rows (rows_dev: nullable device scalar). */
+int capdec_layernorm_bwd_rows(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
+                              int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma,
+                              float* dbeta, float* dxsum, const int32_t* rows_dev, void* stream);
 /* out[j] += sum_i x[i*ldx + j] */
 int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream);
 /* The same over the first min(M, rows_dev[0]) rows (rows_dev: nullable device scalar). */
 int capdec_colsum_rows(const float* x, int64_t ldx, int M, int N, float* out, const int32_t* rows_dev, void* stream);
 /* out[g,:] = sum over t < T of x[g*T + t, :]  (gradient of a row that was broadcast over T positions) */
 int capdec_group_sum(const float* x, int G, int T, int E, float* out, void* stream);
+/* out[g,:] = sum of the rows [seg_off[g], seg_off[g+1]) of x (seg_off: device, G+1 entries) */
+int capdec_group_sum_segments(const float* x, int G, const int32_t* seg_off, int E, float* out, void* stream);
 /* demb[ids[r],:] += dx[r,:]  (nn.Embedding backward, transformer.py:126 / cnnrnn_model.py:27) */
 int capdec_embed_bwd(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb, void* stream);
+/* The same over the first min(rows, rows_dev[0]) rows (rows_dev: nullable device scalar). */
+int capdec_embed_bwd_rows(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb,
+                          const int32_t* rows_dev, void* stream);
 int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma, const float* save_mean,
                              const float* save_rstd, int B, int C, float* dx, float* dgamma, float* dbeta,
                              void* stream);
@@ -195,6 +215,11 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
                          float* dq, int64_t lddq, float* dk, int64_t lddk, int64_t sdk, float* dv, int64_t lddv,
                          int64_t sdv, int B, int H, int Tq, int Tk, int dkh, int causal, int causal_off,
                          const int32_t* ids, int64_t ldid, void* stream);
+/* Backward of capdec_attention_ragged (same layout; dq, dk, dv rows outside every sample are left untouched). */
+int capdec_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                const float* dout, int64_t ldo, const float* lse, float* dq, int64_t lddq, float* dk,
+                                int64_t lddk, float* dv, int64_t lddv, int B, int H, int T, int dkh, const int32_t* ids,
+                                const int32_t* seq_off, void* stream);
 /* Test hook: sequences up to 64 positions normally take a one-pass kernel that keeps a (b,h) slice in LDS; on != 0
  * forces the general two-pass kernels (any length up to 2048).  Process-wide; not for production use. */
 int capdec_attention_bwd_force_two_pass(int on);
@@ -214,6 +239,18 @@ int capdec_softmax_nll_grad_rows(float* logits, int64_t ld, const int64_t* targe
  * targets_c [M]: targets[order[s]] (ignore_index from slot count on); count [1]: number of counted targets. */
 int capdec_compact_targets(const int64_t* targets, int M, int64_t ignore_index, int64_t* order, int64_t* slot,
                            int64_t* targets_c, int32_t* count, void* stream);
+/* Live prefixes of a padded caption batch, as a ragged batch.  In the teacher-forced decoder (transformer.py:125-132,
+ * causal self-attention) the rows of sample b from its last counted target on feed nothing but ignored loss terms
+ * (train.py:216,254-256), so the whole stack may leave them out.  len[b] = 1 + last position whose target is not
+ * `pad`, or T if an input id inside that prefix equals `pad` (such a query row attends uniformly over all T keys in the
+ * reference, transformer.py:18-22).  ids, targets [B,T].  order [M=B*T]: dense row of slot s; slot [M]: slot of dense
+ * row r, or M for a dead row; seq_off [B+1]: first slot of each sample; sample [M]: sample of slot s; ids_c [M],
+ * targets_c [M]: ids / targets by slot; count [2]: (live rows rounded up to a multiple of 32, live rows).  The slots
+ * between count[1] and count[0] are copies of row 0 with an ignored target: they are computed like live rows, so that
+ * contractions over the rows may read whole k-tiles, and contribute exactly zero to every gradient. */
+int capdec_compact_prefix(const int64_t* ids, const int64_t* targets, int B, int T, int64_t pad, int64_t* order,
+                          int64_t* slot, int32_t* seq_off, int32_t* sample, int32_t* ids_c, int64_t* targets_c,
+                          int32_t* count, void* stream);
 /* sums = (sum of nll, number of counted targets) from capdec_nll_finalize:
  * loss[0] = sums[0] / sums[1] (nn.CrossEntropyLoss mean over non-ignored targets), gscale[0] = 1 / sums[1] */
 int capdec_loss_finish(const float* sums, float* loss, float* gscale, void* stream);

@@ -118,6 +118,72 @@ def test_vocab_loss_skips_ignored_rows(M, frac_pad):
     assert float(outs[True][1][tgt == 0].abs().max() if (tgt == 0).any() else 0.0) == 0.0
 
 
+def _run_stack(dec, enc, caps, ragged):
+    from capdec import autograd as AG
+    from capdec import ops
+    ids, tgt = caps[:, :-1].contiguous(), caps[:, 1:].contiguous()
+    rg = ops.RaggedRows(ids, tgt, 0) if ragged else None
+    x, tape = AG.tf_forward(dec, enc, ids, 0.0, 0, ragged=rg)
+    if ragged:
+        loss, saved = AG.vocab_loss(dec, x, rg.targets_c, rows=rg.rows)
+    else:
+        loss, saved = AG.vocab_loss(dec, x, tgt)
+    grads = {}
+    dx = AG.vocab_loss_bwd(dec, x, saved, grads)
+    denc = AG.tf_backward(dec, tape, dx, grads)
+    return loss, denc, grads, rg
+
+
+def test_f4_ragged_stack_against_golden():
+    """The decoder stack on the live rows only (one memory row): loss and every gradient against the golden vectors."""
+    fx = load_golden("f4_decoder_forward")
+    dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
+    caps = t(fx["captions"]).cuda()
+    loss, denc, grads, rg = _run_stack(dec, t(fx["enc_S1"]).cuda(), caps, True)
+    close(loss[0], fx["loss_S1"], rtol=1e-5, what="loss")
+    close(denc, fx["denc_S1"], what="denc")
+    names = [n for n, _ in dec.named_parameters()]
+    atol = _noise_floor(fx, "grad__{}@S1", names)
+    for name in names:
+        close(grads[name], fx[f"grad__{name}@S1"], atol=atol, what=name)
+
+
+@pytest.mark.parametrize("B,T", [(37, 20), (256, 12), (5, 50)])
+def test_ragged_stack_equals_full_rows(B, T):
+    """Captions of every length, with <PAD> tails, one caption with a <PAD> inside (it keeps its full length: the
+    reference lets that query row attend over all T keys), one empty caption and one that fills all T positions."""
+    fx = load_golden("f4_decoder_forward")
+    dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
+    V, E = dec.fc2.weight.shape[0], dec.fc2.weight.shape[1]
+    g = torch.Generator().manual_seed(B * 100 + T)
+    caps = torch.zeros(B, T + 1, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(0, T, (1,), generator=g))
+        caps[b, 0] = 1
+        caps[b, 1:1 + n] = torch.randint(4, V, (n,), generator=g)
+        caps[b, 1 + n] = 2
+    caps[1, 1:] = 0                                   # nothing but <SOS>: one live row (target <PAD>... none counted)
+    caps[2, 1:] = torch.randint(4, V, (T,), generator=g)   # no <EOS>, no <PAD>: all T rows live
+    caps[3, 1:6] = torch.tensor([7, 0, 9, 11, 2])[:min(5, T)]     # <PAD> inside the caption
+    caps[3, 6:] = 0
+    caps = caps.cuda()
+    enc = torch.randn(B, 1, E, generator=g).cuda()
+    loss_d, denc_d, grads_d, _ = _run_stack(dec, enc, caps, False)
+    loss_r, denc_r, grads_r, rg = _run_stack(dec, enc, caps, True)
+    counts = rg.counts.cpu()
+    live = int(counts[1])
+    assert int(counts[0]) == min(B * T, (live + 31) // 32 * 32) and live < B * T
+    off = rg.seq_off.cpu()
+    assert int(off[B]) == live and int(off[4] - off[3]) == T and int(off[3] - off[2]) == T
+    close(loss_r[0], loss_d[0].cpu().numpy(), rtol=1e-6, what="loss")
+    close(denc_r, denc_d.cpu().numpy(), what="denc")
+    # (the key-bias gradients are zero in exact arithmetic -- a softmax ignores a shift of all its scores -- and
+    #  rounding noise in fp32: an absolute floor tied to the largest gradient covers them)
+    floor = 1e-7 * max(float(gd.abs().max()) for gd in grads_d.values())
+    for name, gd in grads_d.items():
+        close(grads_r[name], gd.detach().cpu().numpy(), atol=floor, what=name)
+
+
 def test_f6_cnn_attn_train_mode_batchnorm_and_head_gradients():
     from models.cnnattn_model import CNNAttentionModel
     fx = load_golden("f6_heads")
