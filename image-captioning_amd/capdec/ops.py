@@ -510,11 +510,11 @@ class RaggedRows:
 
 
 def attention_ragged(q, k, v, rr, H, want_lse=False):
-    """Causal self-attention over a ragged batch ``rr`` (RaggedRows); q, k, v [M,E] by slot.  The output rows outside
-    every sample are zero."""
+    """Causal self-attention over a ragged batch ``rr`` (RaggedRows); q, k, v [M,E] by slot.  The output rows between
+    the last sample and ``rr.rows[0]`` are zero, those past it are not written."""
     lib = _lib.load()
     M, E = q.shape
-    out = torch.zeros((M, E), device=q.device, dtype=torch.float32)
+    out = torch.empty((M, E), device=q.device, dtype=torch.float32)
     lse = torch.empty((rr.B, H, rr.T), device=q.device, dtype=torch.float32) if want_lse else None
     _lib.check(lib.capdec_attention_ragged(_chk(q).data_ptr(), _row_stride(q, "q"), _chk(k).data_ptr(), _row_stride(k, "k"),
                                            _chk(v).data_ptr(), _row_stride(v, "v"), out.data_ptr(), E, rr.B, H, rr.T,
@@ -524,10 +524,11 @@ def attention_ragged(q, k, v, rr, H, want_lse=False):
 
 
 def attention_bwd_ragged(q, k, v, dout, lse, rr, H):
-    """Backward of ``attention_ragged``.  Returns (dq, dk, dv) [M,E]; rows outside every sample are zero."""
+    """Backward of ``attention_ragged``.  Returns (dq, dk, dv) [M,E]; the rows between the last sample and
+    ``rr.rows[0]`` are zero, those past it are not written."""
     lib = _lib.load()
     M, E = q.shape
-    d = torch.zeros((3, M, E), device=q.device, dtype=torch.float32)
+    d = torch.empty((3, M, E), device=q.device, dtype=torch.float32)
     _lib.check(lib.capdec_attention_bwd_ragged(_chk(q).data_ptr(), _row_stride(q, "q"), _chk(k).data_ptr(),
                                                _row_stride(k, "k"), _chk(v).data_ptr(), _row_stride(v, "v"),
                                                _chk(dout).data_ptr(), _row_stride(dout, "dout"), _chk(lse).data_ptr(),

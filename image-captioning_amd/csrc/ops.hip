@@ -348,6 +348,15 @@ __global__ __launch_bounds__(256) void attention_short_kernel(AttnArgs a) {
         if (grp == 0) *reinterpret_cast<f32x4*>(a.out + qrow * a.ldo + (int64_t)h * dk + 4 * dl) = acc;
         if (lane == 0 && a.lse) a.lse[((int64_t)b * a.H + h) * a.Tq + i] = mx + logf(sum);
     }
+    if (a.seq_off && b == a.B - 1) {
+        // ragged batch: the slots between the last sample and the next multiple of 32 belong to no sample but are
+        // read by the contractions that follow; this head's columns of those rows are zeroed here
+        const int live = a.seq_off[a.B], upto = min(a.B * a.Tq, (live + 31) / 32 * 32);
+        for (int idx = threadIdx.x; idx < (upto - live) * nv; idx += 256) {
+            const int r = live + idx / nv, c = idx % nv;
+            *reinterpret_cast<f32x4*>(a.out + (int64_t)r * a.ldo + (int64_t)h * dk + 4 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 }
 
 // ---- BatchNorm1d on [B, C] ----------------------------------------------------------------------

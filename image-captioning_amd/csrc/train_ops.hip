@@ -677,6 +677,18 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
             *reinterpret_cast<f32x4*>(dvb + (int64_t)j * a.lddv + (int64_t)h * dk + 4 * dl) = av;
         }
     }
+    if (a.seq_off && b == a.B - 1) {
+        // ragged batch: the slots between the last sample and the next multiple of 32 belong to no sample but are
+        // read by the contractions that follow; this head's columns of those gradient rows are zeroed here
+        const int live = a.seq_off[a.B], upto = min(a.B * a.Tq, (live + 31) / 32 * 32);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int idx = threadIdx.x; idx < (upto - live) * nv; idx += 256) {
+            const int r = live + idx / nv, c = idx % nv;
+            *reinterpret_cast<f32x4*>(a.dq + (int64_t)r * a.lddq + (int64_t)h * dk + 4 * c) = z;
+            *reinterpret_cast<f32x4*>(a.dk + (int64_t)r * a.lddk + (int64_t)h * dk + 4 * c) = z;
+            *reinterpret_cast<f32x4*>(a.dv + (int64_t)r * a.lddv + (int64_t)h * dk + 4 * c) = z;
+        }
+    }
 }
 
 // Long memory, short query block (cross-attention over a token or grid memory: Tq <= 64, any Tk, no mask): one
@@ -969,31 +981,43 @@ __global__ __launch_bounds__(1024) void compact_targets_kernel(const int64_t* __
 // self-attention: a row only sees earlier rows).  len[b] = 1 + last position with a counted target, or T when an
 // input id inside that prefix is <PAD> (the reference lets such a query row attend uniformly over all T keys,
 // transformer.py:18-22, so the sample keeps its full length).  Slots are assigned sample by sample, so each sample's
-// live rows stay contiguous and ordered: a ragged batch.  One workgroup; thread t owns samples t, t+1024, ...
+// live rows stay contiguous and ordered: a ragged batch.  One workgroup of 1024 threads sweeps the [B,T] arrays
+// three times with coalesced loads; the per-sample lengths and offsets live in LDS.
 __global__ __launch_bounds__(1024) void compact_prefix_kernel(const int64_t* __restrict__ ids,
                                                               const int64_t* __restrict__ targets, int B, int T,
                                                               int64_t pad, int64_t* __restrict__ order,
                                                               int64_t* __restrict__ slot, int32_t* __restrict__ seq_off,
                                                               int32_t* __restrict__ sample, int32_t* __restrict__ ids_c,
                                                               int64_t* __restrict__ tgt_c, int32_t* __restrict__ count) {
-    __shared__ int part[1024];
+    extern __shared__ int sm[];            // [B] lengths, [B] offsets, [B] marks, [1024] scan
+    int* len = sm;
+    int* off = sm + B;
+    int* mark = sm + 2 * B;
+    int* part = sm + 3 * B;
     const int t = threadIdx.x;
+    const int M = B * T;
+    for (int b = t; b < B; b += 1024) {
+        len[b] = 0;
+        mark[b] = 0;
+    }
+    __syncthreads();
+    for (int r = t; r < M; r += 1024)
+        if (targets[r] != pad) atomicMax(&len[r / T], r % T + 1);
+    __syncthreads();
+    for (int r = t; r < M; r += 1024)
+        if (ids[r] == pad && r % T < len[r / T]) mark[r / T] = 1;      // a <PAD> input inside the prefix
+    __syncthreads();
+    for (int b = t; b < B; b += 1024)
+        if (mark[b]) len[b] = T;
+    __syncthreads();
+    // exclusive scan of the lengths: thread t owns the samples [t*per, (t+1)*per)
     const int per = (B + 1023) / 1024;
     const int lo = min(B, t * per), hi = min(B, lo + per);
-    const int M = B * T;
-    auto length = [&](int b) {
-        int len = 0;
-        for (int p = T - 1; p >= 0; --p)
-            if (targets[(int64_t)b * T + p] != pad) { len = p + 1; break; }
-        for (int p = 0; p < len; ++p)
-            if (ids[(int64_t)b * T + p] == pad) return T;
-        return len;
-    };
     int n = 0;
-    for (int b = lo; b < hi; ++b) n += length(b);
+    for (int b = lo; b < hi; ++b) n += len[b];
     part[t] = n;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {          // inclusive scan
+    for (int d = 1; d < 1024; d <<= 1) {
         const int v = t >= d ? part[t - d] : 0;
         __syncthreads();
         part[t] += v;
@@ -1003,22 +1027,25 @@ __global__ __launch_bounds__(1024) void compact_prefix_kernel(const int64_t* __r
     const int total32 = min(M, (total + 31) / 32 * 32);
     int at = part[t] - n;
     for (int b = lo; b < hi; ++b) {
-        const int len = length(b);
+        off[b] = at;
         seq_off[b] = at;
-        for (int p = 0; p < T; ++p) {
-            const int64_t r = (int64_t)b * T + p;
-            if (p < len) {
-                order[at] = r;
-                sample[at] = b;
-                ids_c[at] = (int32_t)ids[r];
-                tgt_c[at] = targets[r];
-                slot[r] = at++;
-            } else {
-                slot[r] = M;                      // the caller's all-zero extra row
-            }
-        }
+        at += len[b];
     }
     if (t == 0) seq_off[B] = total;
+    __syncthreads();
+    for (int r = t; r < M; r += 1024) {
+        const int b = r / T, p = r - b * T;
+        if (p < len[b]) {
+            const int s = off[b] + p;
+            order[s] = r;
+            sample[s] = b;
+            ids_c[s] = (int32_t)ids[r];
+            tgt_c[s] = targets[r];
+            slot[r] = s;
+        } else {
+            slot[r] = M;                          // the caller's all-zero extra row
+        }
+    }
     // slots that belong to no sample: copies of row 0 with an ignored target.  Those below the next multiple of
     // 32 are computed like live rows (contractions over the rows read whole k-tiles); their gradients are zero.
     for (int r = total + t; r < M; r += 1024) {
@@ -1312,8 +1339,13 @@ int capdec_compact_prefix(const int64_t* ids, const int64_t* targets, int B, int
                           int32_t* count, void* stream) {
     CAPDEC_REQUIRE(ids && targets && order && slot && seq_off && sample && ids_c && targets_c && count);
     CAPDEC_REQUIRE(B >= 1 && T >= 1 && (int64_t)B * T < INT_MAX);
-    hipLaunchKernelGGL(compact_prefix_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, targets, B, T, pad, order,
-                       slot, seq_off, sample, ids_c, targets_c, count);
+    const size_t smem = ((size_t)3 * B + 1024) * sizeof(int);
+    CAPDEC_REQUIRE(smem <= 144 * 1024);           // B <= 11946: the per-sample bookkeeping lives in LDS
+    static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(compact_prefix_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess;
+    if (!ready) return CAPDEC_EINVAL;
+    hipLaunchKernelGGL(compact_prefix_kernel, dim3(1), dim3(1024), smem, (hipStream_t)stream, ids, targets, B, T, pad,
+                       order, slot, seq_off, sample, ids_c, targets_c, count);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

@@ -143,7 +143,8 @@ int capdec_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, i
                      int causal, int causal_off, const int32_t* ids, int64_t ldid, float* lse, void* stream);
 /* Causal self-attention over a ragged batch (see capdec_compact_prefix): sample b is the rows [seq_off[b], seq_off[b+1])
  * of q, k, v, out (row strides ld*) and of ids (nullable; <PAD> query rows as in capdec_attention).  T = the longest
- * possible sample (<= 64); lse [B,H,T] nullable. */
+ * possible sample (<= 64); lse [B,H,T] nullable.  The rows from seq_off[B] up to the next multiple of 32 (capped at
+ * B*T) are zeroed, later rows are not written. */
 int capdec_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                             float* out, int64_t ldo, int B, int H, int T, int dk, const int32_t* ids,
                             const int32_t* seq_off, float* lse, void* stream);
@@ -215,7 +216,8 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
                          float* dq, int64_t lddq, float* dk, int64_t lddk, int64_t sdk, float* dv, int64_t lddv,
                          int64_t sdv, int B, int H, int Tq, int Tk, int dkh, int causal, int causal_off,
                          const int32_t* ids, int64_t ldid, void* stream);
-/* Backward of capdec_attention_ragged (same layout; dq, dk, dv rows outside every sample are left untouched). */
+/* Backward of capdec_attention_ragged (same layout; the dq, dk, dv rows from seq_off[B] up to the next multiple of 32
+ * are zeroed, later rows are not written). */
 int capdec_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                 const float* dout, int64_t ldo, const float* lse, float* dq, int64_t lddq, float* dk,
                                 int64_t lddk, float* dv, int64_t lddv, int B, int H, int T, int dkh, const int32_t* ids,
