@@ -107,8 +107,8 @@ def train_bench(device, rank, world, steps, warmup, fence, note=lambda m: None, 
             "config": {"workload": f"cfg3 ViT-Attn training, B={Bt}/GPU" + (" (512 sharded)" if strong else "") +
                                    f", T={T}, E={E}, H={H}, L={Lt}, V={V}, "
                                    "memory rows S=1, dropout 0.1, Adam lr 1e-3; caption bodies of 8-19 tokens, "
-                                   "so about 27 % of the targets are <PAD> (ignored by the loss; their rows are "
-                                   "skipped in the vocabulary projection and its backward)", "global_batch": world * Bt,
+                                   "so about 27 % of the positions are <PAD> tails (ignored by the loss; the decoder "
+                                   "stack and the vocabulary projection run on the live rows only)", "global_batch": world * Bt,
                        "grad_allreduce_bytes": tr.grad_bytes()},
             "algorithmic_tflops": tflops, "mfma_frac": tflops / (world * FP32_MFMA_PEAK_TFLOPS),
             "loss_first": first, "loss_last": float(loss.item())}

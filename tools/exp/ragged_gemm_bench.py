@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Row-limited contractions (10240-row buffers, 73 % of the rows live) under each tile configuration."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "image-captioning_amd"))
+import torch
+from capdec import _lib, ops
+
+lib = _lib.load()
+
+
+def timeit(fn, reps=40, warm=5):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / reps
+
+
+M, E = 10240, 512
+g = torch.Generator().manual_seed(0)
+x, dy = torch.randn(M, E, generator=g).cuda(), torch.randn(M, E, generator=g).cuda()
+W, b = torch.randn(E, E, generator=g).cuda(), torch.randn(E, generator=g).cuda()
+out, dW = torch.empty(M, E, device="cuda"), torch.zeros(E, E, device="cuda")
+for live in (10240, 7456):
+    rows = torch.tensor([live], dtype=torch.int32, device="cuda")
+    print(f"live rows {live}")
+    for cfg in (0, 116, 11, 216, 22):
+        lib.capdec_gemm_force_config(cfg)
+        f = timeit(lambda: ops.linear(x, W, b, out=out, rows_dev=rows))
+        d = timeit(lambda: ops.linear_dgrad(dy, W, accum=out, rows_dev=rows))
+        w = timeit(lambda: ops.linear_wgrad(dy, x, out=dW, rows_dev=rows))
+        fl = 2.0 * live * E * E / 1e6
+        print(f"  cfg {cfg:3d}: fwd {f:6.1f} us {fl / f:6.1f} TF | dgrad {d:6.1f} us {fl / d:6.1f} TF | wgrad {w:6.1f} us {fl / w:6.1f} TF")
+lib.capdec_gemm_force_config(0)
