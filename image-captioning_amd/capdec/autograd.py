@@ -46,13 +46,18 @@ def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None, bia
 # ---------------------------------------------------------------------------------------------
 # Transformer decoder stack
 # ---------------------------------------------------------------------------------------------
-def ragged_supported(dec, S, T, single_row_shortcut=True):
-    """Whether ``tf_forward`` can run on the live rows only: one memory row (the cross-attention sub-layer is then a
-    per-sample constant) and sequences short enough for the one-workgroup attention kernels."""
+RAGGED_MAX_BATCH = 11946      # the compaction kernel keeps three ints per sample in 144 KiB of LDS
+
+
+def ragged_supported(dec, S, T, B=1):
+    """Whether ``tf_forward`` can run on the live rows only: sequences and memories short enough for the
+    one-workgroup attention kernels (T, S <= 64 and their LDS budgets) and a batch whose per-sample bookkeeping fits
+    the compaction kernel's LDS."""
     E, H = dec.decoder_embedding.weight.shape[1], dec.num_heads
     dk = E // H
-    return (S == 1 and single_row_shortcut and T <= 64 and dk in (16, 32, 64, 128, 256) and
-            (4 * T * (dk + 16) + 2 * T * T) * 4 <= 144 * 1024)
+    return (1 <= S <= 64 and T <= 64 and 1 <= B <= RAGGED_MAX_BATCH and dk in (16, 32, 64, 128, 256) and
+            (4 * T * (dk + 16) + 2 * T * T) * 4 <= 144 * 1024 and
+            (2 * (T + S) * (dk + 16) + 2 * T * S) * 4 <= 144 * 1024 and (2 * S * (dk + 16) + 4 * S) * 4 <= 64 * 1024)
 
 
 def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
@@ -60,7 +65,7 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
     enc [B,S,E] fp32, ids [B,T] int64.  Returns (x [B*T,E] post-LN output of the last layer, tape).
 
     ragged (ops.RaggedRows of the same ids and their targets; needs ``ragged_supported``): the stack runs on the live
-    rows only.  Every [B*T,E] tensor is then indexed by slot, the first ``ragged.rows[0]`` rows exist, and the caller
+    rows only (the memories, and with them the K/V projections of the cross-attention, stay dense).  Every [B*T,E] tensor is then indexed by slot, the first ``ragged.rows[0]`` rows exist, and the caller
     takes the loss against ``ragged.targets_c`` with that row limit.  The dropout masks are drawn per slot."""
     B, S, E = enc.shape
     T = ids.shape[1]
@@ -78,7 +83,7 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
     t.ragged = ragged
     rows = None
     if ragged is not None:
-        if not ragged_supported(dec, S, T, single_row_shortcut) or (ragged.B, ragged.T) != (B, T):
+        if not ragged_supported(dec, S, T, B) or (ragged.B, ragged.T) != (B, T):
             raise RuntimeError("capdec tf_forward: this configuration cannot run on a ragged batch (see ragged_supported)")
         rows = ragged.rows
         x = x.index_select(0, ragged.order)
@@ -111,14 +116,18 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
                                                              sd + _SITE, x_div=T, rows_dev=rows,
                                                              x_map=None if ragged is None else ragged.sample)
         else:
-            c.q2 = ops.linear(c.x1, ca.W_q.weight, ca.W_q.bias)
+            c.q2 = ops.linear(c.x1, ca.W_q.weight, ca.W_q.bias, rows_dev=rows)
             kv2 = torch.empty((2, B * S, E), device=x.device, dtype=torch.float32)
             ops.gemm_groups([dict(P=t.enc, Q=ca.W_k.weight, C=kv2[0], bias_j=ca.W_k.bias),
                              dict(P=t.enc, Q=ca.W_v.weight, C=kv2[1], bias_j=ca.W_v.bias)], E)
             c.kv2 = kv2
-            c.ao2, c.lse2 = ops.attention(c.q2, kv2[0], kv2[1], B, H, T, S, want_lse=True)
-            a2 = ops.linear(c.ao2, ca.W_o.weight, ca.W_o.bias)
-            c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(a2, c.x1, ly.norm2.weight, ly.norm2.bias, p, sd + _SITE)
+            if ragged is not None:
+                c.ao2, c.lse2 = ops.cross_attention_ragged(c.q2, kv2[0], kv2[1], ragged, H, S, want_lse=True)
+            else:
+                c.ao2, c.lse2 = ops.attention(c.q2, kv2[0], kv2[1], B, H, T, S, want_lse=True)
+            a2 = ops.linear(c.ao2, ca.W_o.weight, ca.W_o.bias, rows_dev=rows)
+            c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(a2, c.x1, ly.norm2.weight, ly.norm2.bias, p, sd + _SITE,
+                                                             rows_dev=rows)
         c.h = ops.linear(c.x2, ff.fc1.weight, ff.fc1.bias, relu=True, rows_dev=rows)
         f = ops.linear(c.h, ff.fc2.weight, ff.fc2.bias, rows_dev=rows)
         x, c.s3, c.m3, c.r3 = ops.add_layernorm_train(f, c.x2, ly.norm3.weight, ly.norm3.bias, p, sd + 2 * _SITE,
@@ -162,9 +171,12 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
                            ("W_k.bias", ca.W_k.bias)):
                 _new(grads, pre + "cross_attn." + n, prm)                              # exactly zero
         else:
-            d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2, bias_done=True)
-            dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S, out=c.ao2)
-            _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1)
+            d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2, bias_done=True, rows=rows)
+            if rg is not None:
+                dq2, dk2, dv2 = ops.cross_attention_bwd_ragged(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, rg, H, S)
+            else:
+                dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S, out=c.ao2)
+            _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1, rows=rows)
             _lin_bwd(grads, pre + "cross_attn.W_k", ca.W_k, dk2, t.enc, need_dx=need_denc, accum=denc)
             _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, dv2, t.enc, need_dx=need_denc, accum=denc)
         # x1 = LN1(x + drop(a)),  a = attn(x Wq, x Wk, x Wv; causal, PAD rows) Wo

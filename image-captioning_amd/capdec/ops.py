@@ -538,6 +538,35 @@ def attention_bwd_ragged(q, k, v, dout, lse, rr, H):
     return d[0], d[1], d[2]
 
 
+def cross_attention_ragged(q, k, v, rr, H, S, want_lse=False):
+    """Unmasked attention of the ragged rows q [M,E] (by slot) over the dense memories k, v [B*S,E]."""
+    lib = _lib.load()
+    M, E = q.shape
+    out = torch.empty((M, E), device=q.device, dtype=torch.float32)
+    lse = torch.empty((rr.B, H, rr.T), device=q.device, dtype=torch.float32) if want_lse else None
+    _lib.check(lib.capdec_cross_attention_ragged(_chk(q).data_ptr(), _row_stride(q, "q"), _chk(k).data_ptr(),
+                                                 _row_stride(k, "k"), _chk(v).data_ptr(), _row_stride(v, "v"),
+                                                 out.data_ptr(), E, rr.B, H, rr.T, S, E // H, rr.seq_off.data_ptr(),
+                                                 _ptr(lse), _stream()), "capdec_cross_attention_ragged")
+    return (out, lse) if want_lse else out
+
+
+def cross_attention_bwd_ragged(q, k, v, dout, lse, rr, H, S):
+    """Backward of ``cross_attention_ragged``.  Returns (dq [M,E] by slot, dk, dv [B*S,E])."""
+    lib = _lib.load()
+    M, E = q.shape
+    dq = torch.empty((M, E), device=q.device, dtype=torch.float32)
+    dkv = torch.empty((2, rr.B * S, E), device=q.device, dtype=torch.float32)
+    _lib.check(lib.capdec_cross_attention_bwd_ragged(_chk(q).data_ptr(), _row_stride(q, "q"), _chk(k).data_ptr(),
+                                                     _row_stride(k, "k"), _chk(v).data_ptr(), _row_stride(v, "v"),
+                                                     _chk(dout).data_ptr(), _row_stride(dout, "dout"),
+                                                     _chk(lse).data_ptr(), dq.data_ptr(), E, dkv[0].data_ptr(), E,
+                                                     dkv[1].data_ptr(), E, rr.B, H, rr.T, S, E // H,
+                                                     rr.seq_off.data_ptr(), _stream()),
+               "capdec_cross_attention_bwd_ragged")
+    return dq, dkv[0], dkv[1]
+
+
 def softmax_nll_grad_(logits, targets, ignore_index=0, rows_dev=None):
     """In place: logits [M,V] -> d(mean NLL)/d(logits).  Returns (sums [2] = (sum nll, n counted), gscale [1]).
     rows_dev: int32 device scalar; only the first rows_dev[0] rows hold logits (see capdec_softmax_nll_grad_rows)."""

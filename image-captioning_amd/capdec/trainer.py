@@ -182,7 +182,7 @@ class CaptionTrainer:
         B = feats.shape[0]
         enc = y.view(B, len(parts), -1)
         rg = None
-        if self.skip_dead_rows and AG.ragged_supported(model, enc.shape[1], ids.shape[1]):
+        if self.skip_dead_rows and AG.ragged_supported(model, enc.shape[1], ids.shape[1], B):
             rg = ops.RaggedRows(ids, tgt, self.pad_idx)
         x, tape = AG.tf_forward(model, enc, ids, p, AG.draw_seed() if p > 0 else 0, ragged=rg)
         if rg is not None:

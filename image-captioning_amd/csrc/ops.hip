@@ -157,8 +157,10 @@ struct AttnArgs {
     // row-list form (decode steps): Tq == 1, query/output row r, sample and position from row_map[r]
     const int32_t* row_map; int map_div;     // b = row_map[r] / map_div, position = row_map[r] % map_div
     const int32_t* rows_dev;                 // nullable device scalar: only rows r < rows_dev[0] are live
-    // ragged self-attention (short kernel only): sample b is the rows [seq_off[b], seq_off[b+1]) of q, k, v, out and ids
+    // ragged batch (short kernel only): sample b is the rows [seq_off[b], seq_off[b+1]) of q, out and ids -- and of k, v
+    // too (self-attention) unless ragged_q_only, where k, v stay Tk dense rows per sample (cross-attention)
     const int32_t* seq_off;
+    int ragged_q_only;
 };
 
 template <int NM>
@@ -277,9 +279,12 @@ __global__ __launch_bounds__(256) void attention_short_kernel(AttnArgs a) {
     const float* vb = a.v + (int64_t)b * a.sv;
     if (a.seq_off) {
         q0 = id0 = a.seq_off[b];
-        Tq = Tk = min(a.Tk, a.seq_off[b + 1] - a.seq_off[b]);
-        kb = a.k + q0 * a.ldk;
-        vb = a.v + q0 * a.ldv;
+        Tq = min(a.Tq, a.seq_off[b + 1] - a.seq_off[b]);
+        if (!a.ragged_q_only) {
+            Tk = Tq;
+            kb = a.k + q0 * a.ldk;
+            vb = a.v + q0 * a.ldv;
+        }
     }
     for (int idx = threadIdx.x; idx < Tk * nv; idx += 256) {
         const int r = idx / nv, c = idx - r * nv;
@@ -566,6 +571,27 @@ int capdec_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t
     const size_t short_lds = ((size_t)2 * T * (dk + 16) + 4 * (size_t)T) * sizeof(float);
     CAPDEC_REQUIRE(short_lds <= 64 * 1024);
     AttnArgs a{q, ldq, k, ldk, 0, v, ldv, 0, out, ldo, B, H, T, T, dk, 1, 0, ids, 0, lse, nullptr, 1, nullptr, seq_off};
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attention_short_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), short_lds, (hipStream_t)stream, a)
+    CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
+#undef CAPDEC_CALL
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_cross_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                  float* out, int64_t ldo, int B, int H, int T, int S, int dk, const int32_t* seq_off,
+                                  float* lse, void* stream) {
+    CAPDEC_REQUIRE(q && k && v && out && seq_off && B >= 0 && H >= 1 && T >= 1 && T <= 64 && S >= 1 && S <= 64);
+    CAPDEC_REQUIRE(dk == 16 || dk == 32 || dk == 64 || dk == 128 || dk == 256);
+    if (!capdec_aligned16(q) || !capdec_aligned16(k) || !capdec_aligned16(v) || !capdec_aligned16(out) || ldq % 4 ||
+        ldk % 4 || ldv % 4 || ldo % 4)
+        return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    const size_t short_lds = ((size_t)2 * S * (dk + 16) + 4 * (size_t)S) * sizeof(float);
+    CAPDEC_REQUIRE(short_lds <= 64 * 1024);
+    AttnArgs a{q, ldq, k, ldk, (int64_t)S * ldk, v, ldv, (int64_t)S * ldv, out, ldo, B, H, T, S, dk, 0, 0, nullptr, 0, lse,
+               nullptr, 1, nullptr, seq_off, 1};
 #define CAPDEC_CALL(NM_) \
     hipLaunchKernelGGL(attention_short_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), short_lds, (hipStream_t)stream, a)
     CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);

@@ -396,8 +396,10 @@ struct AttnBwdArgs {
     int B, H, Tq, Tk, dk_;
     int causal, causal_off;
     const int32_t* ids; int64_t ldid;
-    // ragged self-attention (fused kernel only): sample b is the rows [seq_off[b], seq_off[b+1]) of every operand and ids
+    // ragged batch (fused kernel only): sample b is the rows [seq_off[b], seq_off[b+1]) of q, dout, dq and ids -- and of
+    // k, v, dk, dv too (self-attention) unless ragged_q_only, where those stay Tk dense rows per sample (cross-attention)
     const int32_t* seq_off;
+    int ragged_q_only;
 };
 
 template <int NM>
@@ -580,11 +582,14 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
     float* dvb = a.dv + (int64_t)b * a.sdv;
     if (a.seq_off) {
         q0 = id0 = a.seq_off[b];
-        Tq = Tk = min(a.Tk, a.seq_off[b + 1] - a.seq_off[b]);
-        kb = a.k + q0 * a.ldk;
-        vb = a.v + q0 * a.ldv;
-        dkb = a.dk + q0 * a.lddk;
-        dvb = a.dv + q0 * a.lddv;
+        Tq = min(a.Tq, a.seq_off[b + 1] - a.seq_off[b]);
+        if (!a.ragged_q_only) {
+            Tk = Tq;
+            kb = a.k + q0 * a.ldk;
+            vb = a.v + q0 * a.ldv;
+            dkb = a.dk + q0 * a.lddk;
+            dvb = a.dv + q0 * a.lddv;
+        }
     }
     for (int idx = threadIdx.x; idx < Tq * nv; idx += 256) {
         const int r = idx / nv, c = idx - r * nv;
@@ -685,8 +690,10 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
         for (int idx = threadIdx.x; idx < (upto - live) * nv; idx += 256) {
             const int r = live + idx / nv, c = idx % nv;
             *reinterpret_cast<f32x4*>(a.dq + (int64_t)r * a.lddq + (int64_t)h * dk + 4 * c) = z;
-            *reinterpret_cast<f32x4*>(a.dk + (int64_t)r * a.lddk + (int64_t)h * dk + 4 * c) = z;
-            *reinterpret_cast<f32x4*>(a.dv + (int64_t)r * a.lddv + (int64_t)h * dk + 4 * c) = z;
+            if (!a.ragged_q_only) {
+                *reinterpret_cast<f32x4*>(a.dk + (int64_t)r * a.lddk + (int64_t)h * dk + 4 * c) = z;
+                *reinterpret_cast<f32x4*>(a.dv + (int64_t)r * a.lddv + (int64_t)h * dk + 4 * c) = z;
+            }
         }
     }
 }
@@ -1208,7 +1215,41 @@ int capdec_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int
     const size_t fused_lds = ((size_t)4 * T * (dkh + 16) + (size_t)2 * T * T) * sizeof(float);
     CAPDEC_REQUIRE(fused_lds <= 144 * 1024);
     AttnBwdArgs a{q, ldq, k, ldk, 0, v, ldv, 0, dout, ldo, nullptr, 0, lse, nullptr, dq, lddq, dk, lddk, 0, dv, lddv, 0,
-                  B, H, T, T, dkh, 1, 0, ids, 0, seq_off};
+                  B, H, T, T, dkh, 1, 0, ids, 0, seq_off, 0};
+    static const bool ready = [] {
+        bool ok = true;
+#define CAPDEC_CALL(NM_)                                                                                    \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NM_>),               \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess
+        CAPDEC_CALL(1); CAPDEC_CALL(2); CAPDEC_CALL(4); CAPDEC_CALL(8); CAPDEC_CALL(16);
+#undef CAPDEC_CALL
+        return ok;
+    }();
+    if (!ready) return CAPDEC_EINVAL;
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), fused_lds, (hipStream_t)stream, a)
+    CAPDEC_DK_DISPATCH(dkh, CAPDEC_CALL);
+#undef CAPDEC_CALL
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_cross_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                      int64_t ldv, const float* dout, int64_t ldo, const float* lse, float* dq,
+                                      int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, int B, int H, int T,
+                                      int S, int dkh, const int32_t* seq_off, void* stream) {
+    CAPDEC_REQUIRE(q && k && v && dout && lse && dq && dk && dv && seq_off && B >= 0 && H >= 1 && T >= 1 && T <= 64 &&
+                   S >= 1 && S <= 64);
+    CAPDEC_REQUIRE(dkh == 16 || dkh == 32 || dkh == 64 || dkh == 128 || dkh == 256);
+    if (!capdec_aligned16(q) || !capdec_aligned16(k) || !capdec_aligned16(v) || !capdec_aligned16(dout) ||
+        !capdec_aligned16(dq) || !capdec_aligned16(dk) || !capdec_aligned16(dv) || ldq % 4 || ldk % 4 || ldv % 4 ||
+        ldo % 4 || lddq % 4 || lddk % 4 || lddv % 4)
+        return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    const size_t fused_lds = ((size_t)2 * (T + S) * (dkh + 16) + (size_t)2 * T * S) * sizeof(float);
+    CAPDEC_REQUIRE(fused_lds <= 144 * 1024);
+    AttnBwdArgs a{q, ldq, k, ldk, (int64_t)S * ldk, v, ldv, (int64_t)S * ldv, dout, ldo, nullptr, 0, lse, nullptr, dq, lddq,
+                  dk, lddk, (int64_t)S * lddk, dv, lddv, (int64_t)S * lddv, B, H, T, S, dkh, 0, 0, nullptr, 0, seq_off, 1};
     static const bool ready = [] {
         bool ok = true;
 #define CAPDEC_CALL(NM_)                                                                                    \

@@ -148,6 +148,11 @@ int capdec_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, i
 int capdec_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                             float* out, int64_t ldo, int B, int H, int T, int dk, const int32_t* ids,
                             const int32_t* seq_off, float* lse, void* stream);
+/* Cross-attention of a ragged batch over dense memories: q, out by slot as above; k, v hold S rows per sample
+ * ([B*S, .], row strides ldk / ldv); no mask (transformer.py:84: cross_attn(x, enc, enc, None)).  T, S <= 64. */
+int capdec_cross_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                  float* out, int64_t ldo, int B, int H, int T, int S, int dk, const int32_t* seq_off,
+                                  float* lse, void* stream);
 
 /* BatchNorm1d over [B,C] (cnnattn_model.py:13,29; vitattn_model.py:29,45; vitcnnattn_model.py:33,51;
  * yolocnnattn_model.py:61,79; cnnrnn_model.py:14,24).
@@ -222,6 +227,11 @@ int capdec_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int
                                 const float* dout, int64_t ldo, const float* lse, float* dq, int64_t lddq, float* dk,
                                 int64_t lddk, float* dv, int64_t lddv, int B, int H, int T, int dkh, const int32_t* ids,
                                 const int32_t* seq_off, void* stream);
+/* Backward of capdec_cross_attention_ragged: dq by slot (tail rows zeroed as above), dk / dv dense [B*S, .]. */
+int capdec_cross_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                      int64_t ldv, const float* dout, int64_t ldo, const float* lse, float* dq,
+                                      int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, int B, int H, int T,
+                                      int S, int dkh, const int32_t* seq_off, void* stream);
 /* Test hook: sequences up to 64 positions normally take a one-pass kernel that keeps a (b,h) slice in LDS; on != 0
  * forces the general two-pass kernels (any length up to 2048).  Process-wide; not for production use. */
 int capdec_attention_bwd_force_two_pass(int on);

@@ -118,12 +118,12 @@ def test_vocab_loss_skips_ignored_rows(M, frac_pad):
     assert float(outs[True][1][tgt == 0].abs().max() if (tgt == 0).any() else 0.0) == 0.0
 
 
-def _run_stack(dec, enc, caps, ragged):
+def _run_stack(dec, enc, caps, ragged, shortcut=True):
     from capdec import autograd as AG
     from capdec import ops
     ids, tgt = caps[:, :-1].contiguous(), caps[:, 1:].contiguous()
     rg = ops.RaggedRows(ids, tgt, 0) if ragged else None
-    x, tape = AG.tf_forward(dec, enc, ids, 0.0, 0, ragged=rg)
+    x, tape = AG.tf_forward(dec, enc, ids, 0.0, 0, single_row_shortcut=shortcut, ragged=rg)
     if ragged:
         loss, saved = AG.vocab_loss(dec, x, rg.targets_c, rows=rg.rows)
     else:
@@ -134,22 +134,24 @@ def _run_stack(dec, enc, caps, ragged):
     return loss, denc, grads, rg
 
 
-def test_f4_ragged_stack_against_golden():
-    """The decoder stack on the live rows only (one memory row): loss and every gradient against the golden vectors."""
+@pytest.mark.parametrize("S,shortcut", [(1, True), (1, False), (2, True), (5, True)])
+def test_f4_ragged_stack_against_golden(S, shortcut):
+    """The decoder stack on the live rows only: loss and every gradient against the golden vectors (one memory row
+    through the closed form and through the general cross-attention kernels; two and five memory rows)."""
     fx = load_golden("f4_decoder_forward")
     dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
     caps = t(fx["captions"]).cuda()
-    loss, denc, grads, rg = _run_stack(dec, t(fx["enc_S1"]).cuda(), caps, True)
-    close(loss[0], fx["loss_S1"], rtol=1e-5, what="loss")
-    close(denc, fx["denc_S1"], what="denc")
+    loss, denc, grads, rg = _run_stack(dec, t(fx[f"enc_S{S}"]).cuda(), caps, True, shortcut)
+    close(loss[0], fx[f"loss_S{S}"], rtol=1e-5, what="loss")
+    close(denc, fx[f"denc_S{S}"], what="denc")
     names = [n for n, _ in dec.named_parameters()]
-    atol = _noise_floor(fx, "grad__{}@S1", names)
+    atol = _noise_floor(fx, "grad__{}@S" + str(S), names)
     for name in names:
-        close(grads[name], fx[f"grad__{name}@S1"], atol=atol, what=name)
+        close(grads[name], fx[f"grad__{name}@S{S}"], atol=atol, what=name)
 
 
-@pytest.mark.parametrize("B,T", [(37, 20), (256, 12), (5, 50)])
-def test_ragged_stack_equals_full_rows(B, T):
+@pytest.mark.parametrize("B,T,S", [(37, 20, 1), (256, 12, 1), (5, 50, 1), (37, 20, 2), (64, 20, 64)])
+def test_ragged_stack_equals_full_rows(B, T, S):
     """Captions of every length, with <PAD> tails, one caption with a <PAD> inside (it keeps its full length: the
     reference lets that query row attend over all T keys), one empty caption and one that fills all T positions."""
     fx = load_golden("f4_decoder_forward")
@@ -167,7 +169,7 @@ def test_ragged_stack_equals_full_rows(B, T):
     caps[3, 1:6] = torch.tensor([7, 0, 9, 11, 2])[:min(5, T)]     # <PAD> inside the caption
     caps[3, 6:] = 0
     caps = caps.cuda()
-    enc = torch.randn(B, 1, E, generator=g).cuda()
+    enc = torch.randn(B, S, E, generator=g).cuda()
     loss_d, denc_d, grads_d, _ = _run_stack(dec, enc, caps, False)
     loss_r, denc_r, grads_r, rg = _run_stack(dec, enc, caps, True)
     counts = rg.counts.cpu()
