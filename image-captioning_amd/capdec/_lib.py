@@ -105,8 +105,10 @@ _SIGNATURES = {
                                         _P, _P, _P]),
     "capdec_cross_attention_ragged": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int,
                                               c_int, _P, _P, _P]),
-    "capdec_cross_attention_bwd_ragged": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P,
-                                                  c_int64, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "capdec_cross_attention_bwd_ragged": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P,
+                                                  c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                                  _P, _P]),
+    "capdec_attention_force_row_kernel": (c_int, [c_int]),
     "capdec_attention_bwd_ragged": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64,
                                             _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "capdec_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P]),

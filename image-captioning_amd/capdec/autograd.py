@@ -50,14 +50,19 @@ RAGGED_MAX_BATCH = 11946      # the compaction kernel keeps three ints per sampl
 
 
 def ragged_supported(dec, S, T, B=1):
-    """Whether ``tf_forward`` can run on the live rows only: sequences and memories short enough for the
-    one-workgroup attention kernels (T, S <= 64 and their LDS budgets) and a batch whose per-sample bookkeeping fits
-    the compaction kernel's LDS."""
+    """Whether ``tf_forward`` can run on the live rows only: sequences short enough for the one-workgroup attention
+    kernels (T <= 64 and their LDS budgets, memories up to 2048 rows) and a batch whose per-sample bookkeeping fits the
+    compaction kernel's LDS."""
     E, H = dec.decoder_embedding.weight.shape[1], dec.num_heads
     dk = E // H
-    return (1 <= S <= 64 and T <= 64 and 1 <= B <= RAGGED_MAX_BATCH and dk in (16, 32, 64, 128, 256) and
-            (4 * T * (dk + 16) + 2 * T * T) * 4 <= 144 * 1024 and
-            (2 * (T + S) * (dk + 16) + 2 * T * S) * 4 <= 144 * 1024 and (2 * S * (dk + 16) + 4 * S) * 4 <= 64 * 1024)
+    if not (T <= 64 and 1 <= B <= RAGGED_MAX_BATCH and dk in (16, 32, 64, 128, 256) and
+            (4 * T * (dk + 16) + 2 * T * T) * 4 <= 144 * 1024):
+        return False
+    if 1 <= S <= 64:       # cross-attention with the memory of a sample resident in LDS
+        return (2 * (T + S) * (dk + 16) + 2 * T * S) * 4 <= 144 * 1024 and (2 * S * (dk + 16) + 4 * S) * 4 <= 64 * 1024
+    # longer memories: keys streamed through LDS in chunks of 32
+    return (S <= 2048 and T >= 4 and ((3 * T + 64) * (dk + 16) + 64 * T + 2 * T) * 4 <= 144 * 1024 and
+            ((T + 64) * (dk + 16) + 128) * 4 <= 144 * 1024)
 
 
 def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
@@ -173,7 +178,7 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         else:
             d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2, bias_done=True, rows=rows)
             if rg is not None:
-                dq2, dk2, dv2 = ops.cross_attention_bwd_ragged(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, rg, H, S)
+                dq2, dk2, dv2 = ops.cross_attention_bwd_ragged(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, rg, H, S, out=c.ao2)
             else:
                 dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S, out=c.ao2)
             _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1, rows=rows)

@@ -551,15 +551,17 @@ def cross_attention_ragged(q, k, v, rr, H, S, want_lse=False):
     return (out, lse) if want_lse else out
 
 
-def cross_attention_bwd_ragged(q, k, v, dout, lse, rr, H, S):
-    """Backward of ``cross_attention_ragged``.  Returns (dq [M,E] by slot, dk, dv [B*S,E])."""
+def cross_attention_bwd_ragged(q, k, v, dout, lse, rr, H, S, out=None):
+    """Backward of ``cross_attention_ragged``.  Returns (dq [M,E] by slot, dk, dv [B*S,E]).  ``out`` (the forward
+    output) is needed for memories longer than 64 rows."""
     lib = _lib.load()
     M, E = q.shape
     dq = torch.empty((M, E), device=q.device, dtype=torch.float32)
     dkv = torch.empty((2, rr.B * S, E), device=q.device, dtype=torch.float32)
     _lib.check(lib.capdec_cross_attention_bwd_ragged(_chk(q).data_ptr(), _row_stride(q, "q"), _chk(k).data_ptr(),
                                                      _row_stride(k, "k"), _chk(v).data_ptr(), _row_stride(v, "v"),
-                                                     _chk(dout).data_ptr(), _row_stride(dout, "dout"),
+                                                     _chk(dout).data_ptr(), _row_stride(dout, "dout"), _ptr(out),
+                                                     0 if out is None else _row_stride(out, "out"),
                                                      _chk(lse).data_ptr(), dq.data_ptr(), E, dkv[0].data_ptr(), E,
                                                      dkv[1].data_ptr(), E, rr.B, H, rr.T, S, E // H,
                                                      rr.seq_off.data_ptr(), _stream()),

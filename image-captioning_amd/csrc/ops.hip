@@ -364,6 +364,126 @@ __global__ __launch_bounds__(256) void attention_short_kernel(AttnArgs a) {
     }
 }
 
+// Long unmasked memories with several query rows per sample (cross-attention over a token or grid memory: 4 <= Tq <= 64,
+// Tk > 64): one workgroup per (b,h) keeps that head's queries in LDS and streams the keys and values through LDS in
+// chunks of AL_KC rows, each read from memory once; every wavefront carries the running maximum, the running sum and
+// the un-normalised output of its query rows from chunk to chunk (the softmax is rescaled whenever the maximum grows).
+// Rows may be ragged on the query side (seq_off, ragged_q_only) exactly as in attention_short_kernel.
+constexpr int AL_KC = 32;
+
+template <int NM, int RPW>
+__global__ __launch_bounds__(256) void attention_long_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dk = a.dk, LD = dk + 16, Tk = a.Tk;
+    float* Qs = lds;                       // [a.Tq][LD]
+    float* Ks = Qs + a.Tq * LD;            // [AL_KC][LD]
+    float* Vs = Ks + AL_KC * LD;           // [AL_KC][LD]
+    float* sc = Vs + AL_KC * LD + wave * AL_KC;     // this wavefront's scores of the chunk
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int nv = dk / 4;
+    int Tq = a.Tq;
+    int64_t q0 = (int64_t)b * Tq;
+    if (a.seq_off) {
+        q0 = a.seq_off[b];
+        Tq = min(a.Tq, a.seq_off[b + 1] - a.seq_off[b]);
+    }
+    const float* kb = a.k + (int64_t)b * a.sk + (int64_t)h * dk;
+    const float* vb = a.v + (int64_t)b * a.sv + (int64_t)h * dk;
+    for (int idx = threadIdx.x; idx < Tq * nv; idx += 256) {
+        const int r = idx / nv, c = idx - r * nv;
+        *reinterpret_cast<f32x4*>(&Qs[r * LD + 4 * c]) =
+            *reinterpret_cast<const f32x4*>(a.q + (q0 + r) * a.ldq + (int64_t)h * dk + 4 * c);
+    }
+    const float scale = sqrtf((float)dk);
+    const int part = lane & 3, kl = lane >> 2;
+    const int lpv = dk / 4, grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
+    float mrow[RPW], lrow[RPW];
+    f32x4 acc[RPW];
+#pragma unroll
+    for (int n = 0; n < RPW; ++n) {
+        mrow[n] = -INFINITY;
+        lrow[n] = 0.f;
+        acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int c0 = 0; c0 < Tk; c0 += AL_KC) {
+        const int nk = min(AL_KC, Tk - c0);
+        __syncthreads();                   // the previous chunk is consumed (and the queries are staged)
+        for (int idx = threadIdx.x; idx < nk * nv; idx += 256) {
+            const int r = idx / nv, c = idx - r * nv;
+            *reinterpret_cast<f32x4*>(&Ks[r * LD + 4 * c]) =
+                *reinterpret_cast<const f32x4*>(kb + (int64_t)(c0 + r) * a.ldk + 4 * c);
+            *reinterpret_cast<f32x4*>(&Vs[r * LD + 4 * c]) =
+                *reinterpret_cast<const f32x4*>(vb + (int64_t)(c0 + r) * a.ldv + 4 * c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < RPW; ++n) {
+            const int i = wave + 4 * n;
+            if (i >= Tq) break;
+            f32x4 qreg[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) qreg[m] = *reinterpret_cast<const f32x4*>(Qs + i * LD + 4 * part + 16 * m);
+            float cm = -INFINITY;
+            for (int j0 = 0; j0 < nk; j0 += 16) {
+                const int j = j0 + kl;
+                float d = 0.f;
+                if (j < nk) {
+                    const float* kp = Ks + j * LD + 4 * part;
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 16 * m);
+                        d += qreg[m][0] * kk[0] + qreg[m][1] * kk[1] + qreg[m][2] * kk[2] + qreg[m][3] * kk[3];
+                    }
+                }
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                d /= scale;
+                if (j < nk) {
+                    cm = fmaxf(cm, d);
+                    if (part == 0) sc[j] = d;
+                }
+            }
+            // LDS serves one wavefront's accesses in order: the scores above are visible to its other lanes
+            const float mnew = fmaxf(mrow[n], wave_max(cm));
+            const float alpha = expf(mrow[n] - mnew);          // 0 on the first chunk (exp(-inf))
+            float ps = 0.f;
+            for (int j = lane; j < nk; j += 64) {
+                const float e = expf(sc[j] - mnew);
+                sc[j] = e;
+                ps += e;
+            }
+            lrow[n] = lrow[n] * alpha + wave_sum(ps);
+            mrow[n] = mnew;
+            f32x4 add = {0.f, 0.f, 0.f, 0.f};
+            for (int j = grp; j < nk; j += ngrp) add += *reinterpret_cast<const f32x4*>(Vs + j * LD + 4 * dl) * sc[j];
+            acc[n] = acc[n] * alpha + add;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < RPW; ++n) {
+        const int i = wave + 4 * n;
+        if (i >= Tq) break;
+        f32x4 o = acc[n];
+        for (int s = lpv; s < 64; s <<= 1) {
+            o[0] += __shfl_xor(o[0], s, 64);
+            o[1] += __shfl_xor(o[1], s, 64);
+            o[2] += __shfl_xor(o[2], s, 64);
+            o[3] += __shfl_xor(o[3], s, 64);
+        }
+        if (grp == 0) *reinterpret_cast<f32x4*>(a.out + (q0 + i) * a.ldo + (int64_t)h * dk + 4 * dl) = o / lrow[n];
+        if (lane == 0 && a.lse) a.lse[((int64_t)b * a.H + h) * a.Tq + i] = mrow[n] + logf(lrow[n]);
+    }
+    if (a.seq_off && b == a.B - 1) {
+        // ragged batch: zero this head's columns of the rows between the last sample and the next multiple of 32
+        const int live = a.seq_off[a.B], upto = min(a.B * a.Tq, (live + 31) / 32 * 32);
+        for (int idx = threadIdx.x; idx < (upto - live) * nv; idx += 256) {
+            const int r = live + idx / nv, c = idx % nv;
+            *reinterpret_cast<f32x4*>(a.out + (int64_t)r * a.ldo + (int64_t)h * dk + 4 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 // ---- BatchNorm1d on [B, C] ----------------------------------------------------------------------
 // eval: fold the running statistics into a per-column scale/shift for a GEMM epilogue
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -444,6 +564,8 @@ __global__ __launch_bounds__(256) void bn_train_kernel(const float* __restrict__
     }
 }
 
+int g_attention_no_long = 0;   // tests: 1 keeps long memories on the one-wavefront-per-row kernel
+
 }  // namespace
 
 // ---- row-list forms used by the decode engine (device-side row count, explicit (sample, position) per row) ----
@@ -475,6 +597,41 @@ int capdec_launch_attention_rows(const float* q, int64_t ldq, const float* k, in
     CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+// the chunked kernel for long unmasked memories; *used is false when the shape is outside its range
+static int launch_attention_long(const AttnArgs& a, hipStream_t s, bool* used) {
+    *used = false;
+    const int Tq = a.Tq, dk = a.dk;
+    if (a.causal || a.ids || a.row_map || Tq < 4 || Tq > 64 || a.Tk <= 64 || g_attention_no_long) return 0;
+    const size_t smem = ((size_t)(Tq + 2 * AL_KC) * (dk + 16) + 4 * AL_KC) * sizeof(float);
+    if (smem > 144 * 1024) return 0;
+    static const bool ready = [] {
+        bool ok = true;
+#define CAPDEC_CALL(NM_)                                                                                              \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<NM_, 4>),                      \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess &&           \
+         hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<NM_, 8>),                            \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess &&                 \
+         hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<NM_, 16>),                           \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess
+        CAPDEC_CALL(1); CAPDEC_CALL(2); CAPDEC_CALL(4); CAPDEC_CALL(8); CAPDEC_CALL(16);
+#undef CAPDEC_CALL
+        return ok;
+    }();
+    if (!ready) return CAPDEC_EINVAL;
+    const dim3 grid((unsigned)(a.B * a.H));
+#define CAPDEC_CALL(NM_)                                                                                       \
+    do {                                                                                                       \
+        if (Tq <= 16) hipLaunchKernelGGL((attention_long_kernel<NM_, 4>), grid, dim3(256), smem, s, a);        \
+        else if (Tq <= 32) hipLaunchKernelGGL((attention_long_kernel<NM_, 8>), grid, dim3(256), smem, s, a);   \
+        else hipLaunchKernelGGL((attention_long_kernel<NM_, 16>), grid, dim3(256), smem, s, a);                \
+    } while (0)
+    CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
+#undef CAPDEC_CALL
+    CAPDEC_LAUNCH_CHECK();
+    *used = true;
     return 0;
 }
 
@@ -549,6 +706,9 @@ int capdec_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, i
         CAPDEC_LAUNCH_CHECK();
         return 0;
     }
+    bool used_long = false;
+    CAPDEC_TRY(launch_attention_long(a, (hipStream_t)stream, &used_long));
+    if (used_long) return 0;
     const long total = (long)B * H * Tq;
 #define CAPDEC_CALL(NM_)                                                                                          \
     hipLaunchKernelGGL(attention_kernel<NM_>, dim3((unsigned)((total + 3) / 4)), dim3(256), 4 * Tk * sizeof(float), \
@@ -582,21 +742,32 @@ int capdec_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t
 int capdec_cross_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                   float* out, int64_t ldo, int B, int H, int T, int S, int dk, const int32_t* seq_off,
                                   float* lse, void* stream) {
-    CAPDEC_REQUIRE(q && k && v && out && seq_off && B >= 0 && H >= 1 && T >= 1 && T <= 64 && S >= 1 && S <= 64);
+    CAPDEC_REQUIRE(q && k && v && out && seq_off && B >= 0 && H >= 1 && T >= 1 && T <= 64 && S >= 1 && S <= 2048);
     CAPDEC_REQUIRE(dk == 16 || dk == 32 || dk == 64 || dk == 128 || dk == 256);
     if (!capdec_aligned16(q) || !capdec_aligned16(k) || !capdec_aligned16(v) || !capdec_aligned16(out) || ldq % 4 ||
         ldk % 4 || ldv % 4 || ldo % 4)
         return CAPDEC_EALIGN;
     if (B == 0) return 0;
-    const size_t short_lds = ((size_t)2 * S * (dk + 16) + 4 * (size_t)S) * sizeof(float);
-    CAPDEC_REQUIRE(short_lds <= 64 * 1024);
     AttnArgs a{q, ldq, k, ldk, (int64_t)S * ldk, v, ldv, (int64_t)S * ldv, out, ldo, B, H, T, S, dk, 0, 0, nullptr, 0, lse,
                nullptr, 1, nullptr, seq_off, 1};
+    if (S > 64) {
+        CAPDEC_REQUIRE(T >= 4 && !g_attention_no_long);       // long memories: the chunked kernel only
+        bool used_long = false;
+        CAPDEC_TRY(launch_attention_long(a, (hipStream_t)stream, &used_long));
+        return used_long ? 0 : CAPDEC_EINVAL;
+    }
+    const size_t short_lds = ((size_t)2 * S * (dk + 16) + 4 * (size_t)S) * sizeof(float);
+    CAPDEC_REQUIRE(short_lds <= 64 * 1024);
 #define CAPDEC_CALL(NM_) \
     hipLaunchKernelGGL(attention_short_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), short_lds, (hipStream_t)stream, a)
     CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_attention_force_row_kernel(int on) {
+    g_attention_no_long = on ? 1 : 0;
     return 0;
 }
 

@@ -708,21 +708,28 @@ template <int NM>
 __global__ __launch_bounds__(256) void attn_bwd_chunked_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int dk = a.dk_, LD = dk + 16, Tq = a.Tq, Tk = a.Tk;
+    const int dk = a.dk_, LD = dk + 16, Tk = a.Tk;
     float* Qs = lds;                       // [Tq][LD]
-    float* Os = Qs + Tq * LD;              // dO [Tq][LD]
-    float* dQs = Os + Tq * LD;             // [Tq][LD]
-    float* Ks = dQs + Tq * LD;             // [AB_KC][LD]
+    float* Os = Qs + a.Tq * LD;            // dO [Tq][LD]
+    float* dQs = Os + a.Tq * LD;           // [Tq][LD]
+    float* Ks = dQs + a.Tq * LD;           // [AB_KC][LD]
     float* Vs = Ks + AB_KC * LD;           // [AB_KC][LD]
     float* Ps = Vs + AB_KC * LD;           // [Tq][AB_KC]
-    float* Ds = Ps + Tq * AB_KC;           // [Tq][AB_KC]
-    float* Dsum = Ds + Tq * AB_KC;         // [Tq]
-    float* Lse = Dsum + Tq;                // [Tq]
+    float* Ds = Ps + a.Tq * AB_KC;         // [Tq][AB_KC]
+    float* Dsum = Ds + a.Tq * AB_KC;       // [Tq]
+    float* Lse = Dsum + a.Tq;              // [Tq]
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
     const int nv = dk / 4;
+    // ragged on the query side: sample b's rows of q, dout, out and dq are [seq_off[b], seq_off[b+1]); k, v stay dense
+    int Tq = a.Tq;
+    int64_t q0 = (int64_t)b * Tq;
+    if (a.seq_off) {
+        q0 = a.seq_off[b];
+        Tq = min(a.Tq, a.seq_off[b + 1] - a.seq_off[b]);
+    }
     for (int idx = threadIdx.x; idx < Tq * nv; idx += 256) {
         const int r = idx / nv, c = idx - r * nv;
-        const int64_t row = (int64_t)b * Tq + r;
+        const int64_t row = q0 + r;
         *reinterpret_cast<f32x4*>(&Qs[r * LD + 4 * c]) =
             *reinterpret_cast<const f32x4*>(a.q + row * a.ldq + (int64_t)h * dk + 4 * c);
         *reinterpret_cast<f32x4*>(&Os[r * LD + 4 * c]) =
@@ -731,14 +738,14 @@ __global__ __launch_bounds__(256) void attn_bwd_chunked_kernel(AttnBwdArgs a) {
     }
     // D_i = dO_i . O_i, one wavefront per row
     for (int i = wave; i < Tq; i += 4) {
-        const int64_t row = (int64_t)b * Tq + i;
+        const int64_t row = q0 + i;
         float d = 0.f;
         for (int c = lane; c < dk; c += 64)
             d += a.dout[row * a.ldo + (int64_t)h * dk + c] * a.out[row * a.ldout + (int64_t)h * dk + c];
         d = wave_sum(d);
         if (lane == 0) {
             Dsum[i] = d;
-            Lse[i] = a.lse[((int64_t)b * a.H + h) * Tq + i];
+            Lse[i] = a.lse[((int64_t)b * a.H + h) * a.Tq + i];
         }
     }
     const float scale = sqrtf((float)dk);
@@ -804,8 +811,16 @@ __global__ __launch_bounds__(256) void attn_bwd_chunked_kernel(AttnBwdArgs a) {
     __syncthreads();
     for (int idx = threadIdx.x; idx < Tq * nv; idx += 256) {
         const int r = idx / nv, c = idx - r * nv;
-        *reinterpret_cast<f32x4*>(a.dq + ((int64_t)b * Tq + r) * a.lddq + (int64_t)h * dk + 4 * c) =
+        *reinterpret_cast<f32x4*>(a.dq + (q0 + r) * a.lddq + (int64_t)h * dk + 4 * c) =
             *reinterpret_cast<const f32x4*>(&dQs[r * LD + 4 * c]);
+    }
+    if (a.seq_off && b == a.B - 1) {
+        // ragged batch: zero this head's columns of the dq rows between the last sample and the next multiple of 32
+        const int live = a.seq_off[a.B], upto = min(a.B * a.Tq, (live + 31) / 32 * 32);
+        for (int idx = threadIdx.x; idx < (upto - live) * nv; idx += 256) {
+            const int r = live + idx / nv, c = idx % nv;
+            *reinterpret_cast<f32x4*>(a.dq + (int64_t)r * a.lddq + (int64_t)h * dk + 4 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 }
 
@@ -1235,11 +1250,43 @@ int capdec_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int
 }
 
 int capdec_cross_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
-                                      int64_t ldv, const float* dout, int64_t ldo, const float* lse, float* dq,
-                                      int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, int B, int H, int T,
-                                      int S, int dkh, const int32_t* seq_off, void* stream) {
+                                      int64_t ldv, const float* dout, int64_t ldo, const float* out, int64_t ldout,
+                                      const float* lse, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
+                                      int64_t lddv, int B, int H, int T, int S, int dkh, const int32_t* seq_off,
+                                      void* stream) {
     CAPDEC_REQUIRE(q && k && v && dout && lse && dq && dk && dv && seq_off && B >= 0 && H >= 1 && T >= 1 && T <= 64 &&
-                   S >= 1 && S <= 64);
+                   S >= 1 && S <= 2048);
+    if (S > 64) {
+        // long memories: keys streamed through LDS in chunks; needs the forward output
+        CAPDEC_REQUIRE(out && ldout % 4 == 0 && capdec_aligned16(out));
+        CAPDEC_REQUIRE(dkh == 16 || dkh == 32 || dkh == 64 || dkh == 128 || dkh == 256);
+        if (!capdec_aligned16(q) || !capdec_aligned16(k) || !capdec_aligned16(v) || !capdec_aligned16(dout) ||
+            !capdec_aligned16(dq) || !capdec_aligned16(dk) || !capdec_aligned16(dv) || ldq % 4 || ldk % 4 || ldv % 4 ||
+            ldo % 4 || lddq % 4 || lddk % 4 || lddv % 4)
+            return CAPDEC_EALIGN;
+        if (B == 0) return 0;
+        const size_t chunk_lds = ((size_t)(3 * T + 2 * AB_KC) * (dkh + 16) + (size_t)2 * T * AB_KC + 2 * T) * sizeof(float);
+        CAPDEC_REQUIRE(chunk_lds <= 144 * 1024);
+        AttnBwdArgs a{q, ldq, k, ldk, (int64_t)S * ldk, v, ldv, (int64_t)S * ldv, dout, ldo, out, ldout, lse, nullptr, dq,
+                      lddq, dk, lddk, (int64_t)S * lddk, dv, lddv, (int64_t)S * lddv, B, H, T, S, dkh, 0, 0, nullptr, 0,
+                      seq_off, 1};
+        static const bool ready_c = [] {
+            bool ok = true;
+#define CAPDEC_CALL(NM_)                                                                                    \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_chunked_kernel<NM_>),             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess
+            CAPDEC_CALL(1); CAPDEC_CALL(2); CAPDEC_CALL(4); CAPDEC_CALL(8); CAPDEC_CALL(16);
+#undef CAPDEC_CALL
+            return ok;
+        }();
+        if (!ready_c) return CAPDEC_EINVAL;
+#define CAPDEC_CALL(NM_) \
+    hipLaunchKernelGGL(attn_bwd_chunked_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), chunk_lds, (hipStream_t)stream, a)
+        CAPDEC_DK_DISPATCH(dkh, CAPDEC_CALL);
+#undef CAPDEC_CALL
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
     CAPDEC_REQUIRE(dkh == 16 || dkh == 32 || dkh == 64 || dkh == 128 || dkh == 256);
     if (!capdec_aligned16(q) || !capdec_aligned16(k) || !capdec_aligned16(v) || !capdec_aligned16(dout) ||
         !capdec_aligned16(dq) || !capdec_aligned16(dk) || !capdec_aligned16(dv) || ldq % 4 || ldk % 4 || ldv % 4 ||

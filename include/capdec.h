@@ -149,7 +149,8 @@ int capdec_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t
                             float* out, int64_t ldo, int B, int H, int T, int dk, const int32_t* ids,
                             const int32_t* seq_off, float* lse, void* stream);
 /* Cross-attention of a ragged batch over dense memories: q, out by slot as above; k, v hold S rows per sample
- * ([B*S, .], row strides ldk / ldv); no mask (transformer.py:84: cross_attn(x, enc, enc, None)).  T, S <= 64. */
+ * ([B*S, .], row strides ldk / ldv); no mask (transformer.py:84: cross_attn(x, enc, enc, None)).  T <= 64; S <= 64, or
+ * longer memories (up to 2048 rows) when T >= 4. */
 int capdec_cross_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                   float* out, int64_t ldo, int B, int H, int T, int S, int dk, const int32_t* seq_off,
                                   float* lse, void* stream);
@@ -227,14 +228,19 @@ int capdec_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int
                                 const float* dout, int64_t ldo, const float* lse, float* dq, int64_t lddq, float* dk,
                                 int64_t lddk, float* dv, int64_t lddv, int B, int H, int T, int dkh, const int32_t* ids,
                                 const int32_t* seq_off, void* stream);
-/* Backward of capdec_cross_attention_ragged: dq by slot (tail rows zeroed as above), dk / dv dense [B*S, .]. */
+/* Backward of capdec_cross_attention_ragged: dq by slot (tail rows zeroed as above), dk / dv dense [B*S, .].
+ * out (the forward output, by slot) is required for S > 64 and ignored otherwise. */
 int capdec_cross_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
-                                      int64_t ldv, const float* dout, int64_t ldo, const float* lse, float* dq,
-                                      int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, int B, int H, int T,
-                                      int S, int dkh, const int32_t* seq_off, void* stream);
+                                      int64_t ldv, const float* dout, int64_t ldo, const float* out, int64_t ldout,
+                                      const float* lse, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
+                                      int64_t lddv, int B, int H, int T, int S, int dkh, const int32_t* seq_off,
+                                      void* stream);
 /* Test hook: sequences up to 64 positions normally take a one-pass kernel that keeps a (b,h) slice in LDS; on != 0
  * forces the general two-pass kernels (any length up to 2048).  Process-wide; not for production use. */
 int capdec_attention_bwd_force_two_pass(int on);
+/* Tuning hook for tests: non-zero keeps long unmasked memories (Tk > 64) on the one-wavefront-per-row forward kernel
+ * instead of the chunked one.  Process-wide; not for production use. */
+int capdec_attention_force_row_kernel(int on);
 /* Materialised form of the same loss (train.py:216,254-256) for training, where the backward pass needs the
  * softmax anyway: logits [M,V] (row stride ld) are overwritten in place with d(mean NLL)/d(logits) =
  * (softmax - onehot(target)) / n_counted (zero rows for ignored targets).  sums must be zeroed by the caller:

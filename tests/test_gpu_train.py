@@ -150,7 +150,7 @@ def test_f4_ragged_stack_against_golden(S, shortcut):
         close(grads[name], fx[f"grad__{name}@S{S}"], atol=atol, what=name)
 
 
-@pytest.mark.parametrize("B,T,S", [(37, 20, 1), (256, 12, 1), (5, 50, 1), (37, 20, 2), (64, 20, 64)])
+@pytest.mark.parametrize("B,T,S", [(37, 20, 1), (256, 12, 1), (5, 50, 1), (37, 20, 2), (64, 20, 64), (16, 20, 197)])
 def test_ragged_stack_equals_full_rows(B, T, S):
     """Captions of every length, with <PAD> tails, one caption with a <PAD> inside (it keeps its full length: the
     reference lets that query row attend over all T keys), one empty caption and one that fills all T positions."""
@@ -184,6 +184,32 @@ def test_ragged_stack_equals_full_rows(B, T, S):
     floor = 1e-7 * max(float(gd.abs().max()) for gd in grads_d.values())
     for name, gd in grads_d.items():
         close(grads_r[name], gd.detach().cpu().numpy(), atol=floor, what=name)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,E", [(3, 4, 20, 197, 512), (2, 4, 5, 65, 64), (2, 2, 64, 300, 128), (1, 4, 33, 1000, 256)])
+def test_long_memory_attention_forward_chunked_vs_row_kernel(B, H, Tq, Tk, E):
+    """Unmasked attention over a long memory (transformer.py:13-22 with mask None): the chunked kernel (keys streamed
+    through LDS, running softmax) against fp64 and against the one-wavefront-per-row kernel, output and log-sum-exp."""
+    from capdec import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Tk)
+    q, k, v = (torch.randn(B * n, E, generator=g) for n in (Tq, Tk, Tk))
+    dk = E // H
+    qd, kd, vd = (x.double().view(B, -1, H, dk).transpose(1, 2) for x in (q, k, v))
+    sc = qd @ kd.transpose(-1, -2) / dk ** 0.5
+    ref = (torch.softmax(sc, -1) @ vd).transpose(1, 2).reshape(B * Tq, E)
+    ref_lse = torch.logsumexp(sc, -1)
+    outs = []
+    try:
+        for row_kernel in (0, 1):
+            lib.capdec_attention_force_row_kernel(row_kernel)
+            out, lse = ops.attention(q.cuda(), k.cuda(), v.cuda(), B, H, Tq, Tk, want_lse=True)
+            close(out, ref, what=f"out row_kernel={row_kernel}")
+            close(lse, ref_lse, rtol=1e-5, what=f"lse row_kernel={row_kernel}")
+            outs.append(out)
+    finally:
+        lib.capdec_attention_force_row_kernel(0)
+    close(outs[0], outs[1].cpu().numpy(), rtol=1e-5, what="chunked vs row kernel")
 
 
 def test_f6_cnn_attn_train_mode_batchnorm_and_head_gradients():
