@@ -8,9 +8,10 @@
 //   - a plain store with j contiguous is a 128-byte segment per register (coalesced), and
 //   - any reduction over i (arg-max / log-sum-exp over the vocabulary when P is the vocabulary
 //     matrix) is lane-local: no cross-lane traffic until one final exchange between lane halves.
-// Operand tiles go global -> registers -> LDS (register staging, next tile's loads in flight while
-// the current one is multiplied); LDS rows are padded to 36 floats so the ds_read_b128 fragment
-// reads (32 rows x 16 B per half-wave) are bank-conflict free.
+// Operand tiles reach LDS in one of two ways: written there by the loads themselves (global_load_lds into a
+// linear, XOR-swizzled image: mainloop_dma, taken for aligned operands made of whole k-tiles) or through
+// registers (mainloop: rows padded to BK+4 floats, zero fill for ragged K).  Either way the ds_read_b128
+// fragment reads (32 rows x 16 B per half-wave) are bank-conflict free and the sums run in the same order.
 #include "common.h"
 #include <limits.h>
 #include <math.h>
