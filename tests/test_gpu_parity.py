@@ -459,6 +459,37 @@ def test_gemm_tiles_loaded_straight_into_lds(ops):
         lib.capdec_gemm_force_staging(0)
 
 
+def test_gemm_direct_to_lds_edge_shapes_and_device_limits(ops):
+    """Smallest whole-k-tile shapes, one-row / four-column outputs, and the device-side row and contraction limits
+    (0, inside a tile, across tiles) of the contraction kernels."""
+    from capdec import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(79)
+    try:
+        for cfg in (0, 11, 116, 32, 216):
+            lib.capdec_gemm_force_config(cfg)
+            for (M, N, K) in [(1, 4, 16), (3, 8, 32), (65, 68, 48), (130, 260, 64)]:
+                x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+                close(ops.linear(x.cuda(), W.cuda(), b.cuda()), x.double() @ W.double().t() + b.double(),
+                      what=f"cfg {cfg} {M}x{N}x{K}")
+            x, W = torch.randn(300, 64, generator=g), torch.randn(72, 64, generator=g)
+            for live in (0, 5, 64, 299):
+                rows = torch.tensor([live], dtype=torch.int32, device="cuda")
+                out = torch.full((300, 72), 7.0, device="cuda")
+                ops.linear(x.cuda(), W.cuda(), None, out=out, rows_dev=rows)
+                close(out[:live], x[:live].double() @ W.double().t(), what=f"cfg {cfg} rows {live}")
+                assert bool((out[live:] == 7.0).all()), f"cfg {cfg}: rows past the limit were written"
+            dy, xx = torch.randn(320, 72, generator=g), torch.randn(320, 64, generator=g)
+            for live in (0, 7, 33, 320):
+                rows = torch.tensor([live], dtype=torch.int32, device="cuda")
+                dyz = dy.clone()
+                dyz[live:] = 0                 # the contract: zeros from the limit to the next multiple of 32
+                dw = ops.linear_wgrad(dyz.cuda(), xx.cuda(), rows_dev=rows)
+                close(dw, dy[:live].double().t() @ xx[:live].double(), atol=1e-6, what=f"cfg {cfg} k limit {live}")
+    finally:
+        lib.capdec_gemm_force_config(0)
+
+
 def test_maximum_length_50_forward_greedy_and_beam():
     """The positional-encoding buffer holds 50 positions (transformer.py:58): teacher-forced logits at T=50, and greedy
     and beam decodes of the full 50 steps (cached, exact, with PAD rows mid-sequence) against the oracle."""
