@@ -212,6 +212,59 @@ def test_long_memory_attention_forward_chunked_vs_row_kernel(B, H, Tq, Tk, E):
     close(outs[0], outs[1].cpu().numpy(), rtol=1e-5, what="chunked vs row kernel")
 
 
+@pytest.mark.parametrize("B,T,seed", [(1, 1, 0), (7, 5, 1), (300, 20, 2), (2050, 3, 3), (64, 50, 4)])
+def test_compaction_maps_against_a_python_restatement(B, T, seed):
+    """capdec_compact_prefix / capdec_compact_targets: every output array against a plain Python loop, on random
+    batches with empty captions, <PAD> inside a caption and captions that fill all T positions."""
+    from capdec import ops
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, 6, (B, T), generator=g)          # 0 = <PAD> is frequent: many inside-prefix cases
+    tgt = torch.randint(0, 3, (B, T), generator=g)
+    for b in range(0, B, 3):                                # a third of the samples get a clean <PAD> tail
+        n = int(torch.randint(0, T + 1, (1,), generator=g))
+        ids[b, :n] = torch.randint(1, 6, (n,), generator=g)
+        tgt[b, :n] = torch.randint(1, 3, (n,), generator=g)
+        tgt[b, n:] = 0
+        ids[b, n:] = 0
+    rr = ops.RaggedRows(ids.cuda(), tgt.cuda(), 0)
+    M = B * T
+    lens = []
+    for b in range(B):
+        nz = [p for p in range(T) if int(tgt[b, p]) != 0]
+        n = nz[-1] + 1 if nz else 0
+        if any(int(ids[b, p]) == 0 for p in range(n)):
+            n = T
+        lens.append(n)
+    off = [0]
+    for n in lens:
+        off.append(off[-1] + n)
+    live = off[-1]
+    assert rr.counts.cpu().tolist() == [min(M, (live + 31) // 32 * 32), live]
+    assert rr.seq_off.cpu().tolist() == off
+    order, slot, sample = rr.order.cpu().tolist(), rr.slot.cpu().tolist(), rr.sample.cpu().tolist()
+    ids_c, tgt_c = rr.ids_c.cpu().tolist(), rr.targets_c.cpu().tolist()
+    for b in range(B):
+        for p in range(T):
+            r = b * T + p
+            if p < lens[b]:
+                s_ = off[b] + p
+                assert slot[r] == s_ and order[s_] == r and sample[s_] == b
+                assert ids_c[s_] == int(ids[b, p]) and tgt_c[s_] == int(tgt[b, p])
+            else:
+                assert slot[r] == M
+    assert all(t_ == 0 for t_ in tgt_c[live:]) and all(0 <= o < M for o in order[live:])
+    # loss-level compaction of the flat targets
+    flat = tgt.reshape(-1)
+    o2, s2, t2, c2 = ops.compact_targets(flat.cuda(), 0)
+    keep = [r for r in range(M) if int(flat[r]) != 0]
+    assert int(c2) == len(keep) and o2.cpu().tolist()[:len(keep)] == keep
+    assert t2.cpu().tolist() == [int(flat[r]) for r in keep] + [0] * (M - len(keep))
+    want_slot = [M] * M
+    for k_, r in enumerate(keep):
+        want_slot[r] = k_
+    assert s2.cpu().tolist() == want_slot
+
+
 def test_f6_cnn_attn_train_mode_batchnorm_and_head_gradients():
     from models.cnnattn_model import CNNAttentionModel
     fx = load_golden("f6_heads")
