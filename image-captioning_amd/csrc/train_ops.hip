@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256) void count_targets_kernel(const int64_t* __res
 // them over the wave; pass 2 re-reads the row (cache-resident) and overwrites it with
 // (softmax - onehot(target)) * gscale, or zeros for an ignored target.  The row's NLL joins the workgroup's
 // partial, which leaves as one atomic.
-constexpr int SM_ROWS = 16;
+constexpr int SM_ROWS = 8;
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void softmax_nll_grad_kernel(float* __restrict__ logits, int64_t ld,
