@@ -31,13 +31,42 @@ def _new(grads, name, like):
     return g
 
 
+_SIDE = None      # optional second stream for the weight-gradient contractions (see use_side_stream)
+
+
+def use_side_stream(stream):
+    """Run the weight-gradient contractions (and the bias column sums) of every linear layer on ``stream`` while the
+    input-gradient chain continues on the current stream: the two are independent, and a launch that cannot fill the
+    chip on its own overlaps with the other stream's.  The caller joins the streams (``join_side_stream``) before it
+    reads the gradients.  ``None`` switches the overlap off."""
+    global _SIDE
+    _SIDE = stream
+
+
+def join_side_stream():
+    if _SIDE is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE)
+
+
 def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None, bias_done=False, rows=None):
     """Backward of y = x W^T + b: fills grads[prefix.weight/.bias]; returns dX (added onto ``accum`` if given).
     bias_done: the bias gradient was already accumulated by the kernel that produced dy.
     rows: int32 device scalar (a multiple of 32); only the first rows[0] rows of dy and x exist."""
-    ops.linear_wgrad(dy, x, out=_new(grads, prefix + ".weight", lin.weight), rows_dev=rows)
-    if lin.bias is not None and not bias_done:
-        ops.colsum(dy, _new(grads, prefix + ".bias", lin.bias), rows_dev=rows)
+    gw = _new(grads, prefix + ".weight", lin.weight)
+    gb = _new(grads, prefix + ".bias", lin.bias) if (lin.bias is not None and not bias_done) else None
+    if _SIDE is not None:
+        main = torch.cuda.current_stream()
+        _SIDE.wait_stream(main)                        # dy and x are complete on the main stream
+        with torch.cuda.stream(_SIDE):
+            ops.linear_wgrad(dy, x, out=gw, rows_dev=rows)
+            if gb is not None:
+                ops.colsum(dy, gb, rows_dev=rows)
+        for t in (dy, x):                              # their memory must outlive the side stream's reads
+            t.record_stream(_SIDE)
+    else:
+        ops.linear_wgrad(dy, x, out=gw, rows_dev=rows)
+        if gb is not None:
+            ops.colsum(dy, gb, rows_dev=rows)
     if need_dx:
         return ops.linear_dgrad(dy, lin.weight, mask=mask, accum=accum, rows_dev=rows)
     return None

@@ -9,6 +9,8 @@ batch statistics).  Differences in mechanism, not in result:
     while the rest of the backward pass is still running, and Adam is one kernel over the flat buffers;
   * the [B*T, V] logits are never materialised in the forward pass (fused log-sum-exp + NLL).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -33,15 +35,19 @@ class CaptionTrainer:
     """One object per process (one process per GPU)."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, pad_idx=0, overlap=True,
-                 skip_dead_rows=True):
+                 skip_dead_rows=True, wgrad_stream=None):
         """overlap=True: one async all-reduce per gradient segment, issued as soon as the backward pass has enqueued
         that segment; overlap=False: a single all-reduce of the whole flat gradient buffer after the backward pass.
         skip_dead_rows: run the Transformer stack on the live prefix of every caption only (the positions from a
         caption's last counted target on feed nothing but ignored loss terms); same loss and gradients, the dropout
-        masks are drawn per live row.  Applies where ``autograd.ragged_supported`` holds, else the full rows run."""
+        masks are drawn per live row.  Applies where ``autograd.ragged_supported`` holds, else the full rows run.
+        wgrad_stream: run the weight-gradient contractions on a second HIP stream beside the input-gradient chain
+        (default on; the environment variable CAPDEC_WGRAD_STREAM=0 switches it off when the argument is None)."""
         self.model = model
         self.overlap = overlap
         self.skip_dead_rows = skip_dead_rows
+        self._want_side = (os.environ.get("CAPDEC_WGRAD_STREAM", "1") == "1") if wgrad_stream is None else bool(wgrad_stream)
+        self.side_stream = None
         self.lr, self.betas, self.eps, self.pad_idx = lr, betas, eps, pad_idx
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -56,6 +62,8 @@ class CaptionTrainer:
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("capdec: the trainer needs the model on the GPU (HIP); there is no CPU path")
+        if self._want_side:
+            self.side_stream = torch.cuda.Stream(device=dev)
         # segments in the order the backward pass finishes them
         seg_names = [[n for n in named if n.startswith("fc2.")]]
         if self.rnn is not None:
@@ -116,6 +124,7 @@ class CaptionTrainer:
 
     def _reduce_segment(self, i, works):
         if self.world > 1 and self.overlap:
+            AG.join_side_stream()                      # the segment's weight gradients may still be in flight there
             a, b = self.segments[i]
             if self.host_staged:
                 h = self.flat_g[a:b].cpu()
@@ -135,10 +144,15 @@ class CaptionTrainer:
             self._bcast(self.flat_buf)
         ids = captions[:, :-1].contiguous()
         tgt = captions[:, 1:].contiguous()
-        if self.rnn is not None:
-            loss = self._rnn_step(feats, ids, tgt)
-        else:
-            loss = self._tf_step(feats, ids, tgt)
+        AG.use_side_stream(self.side_stream)
+        try:
+            if self.rnn is not None:
+                loss = self._rnn_step(feats, ids, tgt)
+            else:
+                loss = self._tf_step(feats, ids, tgt)
+            AG.join_side_stream()
+        finally:
+            AG.use_side_stream(None)
         if self.world > 1 and not self.overlap:
             if self.host_staged:
                 h = self.flat_g.cpu()
