@@ -210,11 +210,14 @@ def variants_bench(device, steps=6, warmup=2):
     ragged = AG.ragged_supported(m, St, T, Bt)
     k = [0]
 
+    side = torch.cuda.Stream(device=device)
+
     def tstep():
         k[0] += 1
         tr.flat_g.zero_()
         gw.zero_()
         gb.zero_()
+        AG.use_side_stream(side)           # weight-gradient contractions beside the input-gradient chain, as in CaptionTrainer
         enc = ops.linear(tokens, w_tok, b_tok)
         rg = ops.RaggedRows(ids, tgt, 0) if ragged else None
         x, tape = AG.tf_forward(m, enc.view(Bt, St, E), ids, m.dropout.p, AG.draw_seed(), ragged=rg)
@@ -226,6 +229,8 @@ def variants_bench(device, steps=6, warmup=2):
         denc = AG.tf_backward(m, tape, dx, tr.grads, need_denc=True)
         ops.linear_wgrad(denc.view(Bt * St, E), tokens, out=gw)
         ops.colsum(denc.view(Bt * St, E), gb)
+        AG.join_side_stream()
+        AG.use_side_stream(None)
         ops.adam_step(tr.flat_p, tr.flat_g, tr.m, tr.v, 1e-3, k[0])
         ops.adam_step(w_tok.view(-1), gw.view(-1), mw[:E * Dt], vw[:E * Dt], 1e-3, k[0])
         ops.adam_step(b_tok, gb, mw[E * Dt:], vw[E * Dt:], 1e-3, k[0])
