@@ -125,6 +125,18 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
     if p > 0:
         x = ops.dropout(x, p, seed)
     t.layers = []
+    pre_cc = None
+    if t.shortcut and _SIDE is not None:
+        # the per-sample cross-attention constants depend on enc only: all layers' worth on the side stream now
+        main = torch.cuda.current_stream()
+        _SIDE.wait_stream(main)
+        pre_cc = []
+        with torch.cuda.stream(_SIDE):
+            for ly in dec.decoder_layers:
+                ca = ly.cross_attn
+                v2 = ops.linear(t.enc, ca.W_v.weight, ca.W_v.bias)
+                pre_cc.append((v2, ops.linear(v2, ca.W_o.weight, ca.W_o.bias)))
+        t.enc.record_stream(_SIDE)
     for l, ly in enumerate(dec.decoder_layers):
         c = Tape()
         sd = seed + (3 * l + 1) * _SITE
@@ -144,8 +156,14 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
         if S == 1 and single_row_shortcut:
             # one memory row: the softmax over it is exactly 1, so the sub-layer output is W_o(W_v enc + b_v) + b_o
             # for every position, whatever the query (reference transformer.py:13-22 with Tk = 1)
-            c.v2 = ops.linear(t.enc, ca.W_v.weight, ca.W_v.bias)                       # [B,E]
-            c.cc = ops.linear(c.v2, ca.W_o.weight, ca.W_o.bias)                        # [B,E]
+            if pre_cc is not None:
+                if l == 0:
+                    torch.cuda.current_stream().wait_stream(_SIDE)
+                c.v2, c.cc = pre_cc[l]                                                 # [B,E] each
+                c.cc.record_stream(torch.cuda.current_stream())
+            else:
+                c.v2 = ops.linear(t.enc, ca.W_v.weight, ca.W_v.bias)                   # [B,E]
+                c.cc = ops.linear(c.v2, ca.W_o.weight, ca.W_o.bias)                    # [B,E]
             c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(c.cc, c.x1, ly.norm2.weight, ly.norm2.bias, p,
                                                              sd + _SITE, x_div=T, rows_dev=rows,
                                                              x_map=None if ragged is None else ragged.sample)
@@ -177,6 +195,7 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
     B, S, T, E, H, p = t.B, t.S, t.T, t.E, t.H, t.p
     rg = t.ragged
     rows = None if rg is None else rg.rows
+    side_used = False
     denc = torch.zeros((B * S, E), device=dx.device, dtype=torch.float32) if need_denc else None
     for l in range(len(t.layers) - 1, -1, -1):
         ly, c = dec.decoder_layers[l], t.layers[l]
@@ -198,9 +217,25 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
                                        _new(grads, pre + "norm2.bias", ly.norm2.bias),
                                        dxsum=_new(grads, pre + "cross_attn.W_o.bias", ca.W_o.bias), rows_dev=rows)
         if t.shortcut:
-            d_cc = ops.group_sum(d_a2, T) if rg is None else ops.group_sum_segments(d_a2, rg.seq_off, B)   # [B,E]
-            d_v2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_cc, c.v2, bias_done=True)
-            _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, d_v2, t.enc, need_dx=need_denc, accum=denc)
+            def cross_constant_bwd():
+                d_cc = ops.group_sum(d_a2, T) if rg is None else ops.group_sum_segments(d_a2, rg.seq_off, B)   # [B,E]
+                d_v2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_cc, c.v2, bias_done=True)
+                _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, d_v2, t.enc, need_dx=need_denc, accum=denc)
+            side = _SIDE
+            if side is not None:
+                # nothing on the main chain needs these B-row contractions: the whole sub-chain goes to the side stream
+                side.wait_stream(torch.cuda.current_stream())
+                use_side_stream(None)
+                try:
+                    with torch.cuda.stream(side):
+                        cross_constant_bwd()
+                finally:
+                    use_side_stream(side)
+                for tn in (d_a2, c.v2, t.enc) + ((denc,) if denc is not None else ()):
+                    tn.record_stream(side)
+                side_used = True
+            else:
+                cross_constant_bwd()
             for n, prm in (("W_q.weight", ca.W_q.weight), ("W_q.bias", ca.W_q.bias), ("W_k.weight", ca.W_k.weight),
                            ("W_k.bias", ca.W_k.bias)):
                 _new(grads, pre + "cross_attn." + n, prm)                              # exactly zero
@@ -234,6 +269,8 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         dx = ops.dropout(dx, p, t.seed)
     ops.embed_bwd(t.ids.view(-1) if rg is None else t.ids_c, dx,
                   _new(grads, "decoder_embedding.weight", dec.decoder_embedding.weight), rows_dev=rows)
+    if side_used and need_denc:
+        torch.cuda.current_stream().wait_stream(_SIDE)        # denc was accumulated on the side stream
     return denc.view(B, S, E) if need_denc else None
 
 
