@@ -6,6 +6,8 @@ No ATen arithmetic is used: torch only allocates tensors.  Every saved activatio
 in a ``Tape``; gradients of parameters are written into ``grads[name]`` tensors that the caller may
 pre-allocate (e.g. as views of one flat buffer for a single RCCL all-reduce and a fused Adam step).
 """
+import threading
+
 import torch
 
 from . import _lib, ops
@@ -31,21 +33,24 @@ def _new(grads, name, like):
     return g
 
 
-_SIDE = None      # optional second stream for the weight-gradient contractions (see use_side_stream)
+_TLS = threading.local()      # per host thread: the optional second stream (see use_side_stream)
+
+
+def _side():
+    return getattr(_TLS, "side", None)
 
 
 def use_side_stream(stream):
     """Run the weight-gradient contractions (and the bias column sums) of every linear layer on ``stream`` while the
     input-gradient chain continues on the current stream: the two are independent, and a launch that cannot fill the
     chip on its own overlaps with the other stream's.  The caller joins the streams (``join_side_stream``) before it
-    reads the gradients.  ``None`` switches the overlap off."""
-    global _SIDE
-    _SIDE = stream
+    reads the gradients.  ``None`` switches the overlap off.  The setting belongs to the calling host thread."""
+    _TLS.side = stream
 
 
 def join_side_stream():
-    if _SIDE is not None:
-        torch.cuda.current_stream().wait_stream(_SIDE)
+    if _side() is not None:
+        torch.cuda.current_stream().wait_stream(_side())
 
 
 def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None, bias_done=False, rows=None):
@@ -54,15 +59,15 @@ def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None, bia
     rows: int32 device scalar (a multiple of 32); only the first rows[0] rows of dy and x exist."""
     gw = _new(grads, prefix + ".weight", lin.weight)
     gb = _new(grads, prefix + ".bias", lin.bias) if (lin.bias is not None and not bias_done) else None
-    if _SIDE is not None:
+    if _side() is not None:
         main = torch.cuda.current_stream()
-        _SIDE.wait_stream(main)                        # dy and x are complete on the main stream
-        with torch.cuda.stream(_SIDE):
+        _side().wait_stream(main)                        # dy and x are complete on the main stream
+        with torch.cuda.stream(_side()):
             ops.linear_wgrad(dy, x, out=gw, rows_dev=rows)
             if gb is not None:
                 ops.colsum(dy, gb, rows_dev=rows)
         for t in (dy, x):                              # their memory must outlive the side stream's reads
-            t.record_stream(_SIDE)
+            t.record_stream(_side())
     else:
         ops.linear_wgrad(dy, x, out=gw, rows_dev=rows)
         if gb is not None:
@@ -126,17 +131,17 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
         x = ops.dropout(x, p, seed)
     t.layers = []
     pre_cc = None
-    if t.shortcut and _SIDE is not None:
+    if t.shortcut and _side() is not None:
         # the per-sample cross-attention constants depend on enc only: all layers' worth on the side stream now
         main = torch.cuda.current_stream()
-        _SIDE.wait_stream(main)
+        _side().wait_stream(main)
         pre_cc = []
-        with torch.cuda.stream(_SIDE):
+        with torch.cuda.stream(_side()):
             for ly in dec.decoder_layers:
                 ca = ly.cross_attn
                 v2 = ops.linear(t.enc, ca.W_v.weight, ca.W_v.bias)
                 pre_cc.append((v2, ops.linear(v2, ca.W_o.weight, ca.W_o.bias)))
-        t.enc.record_stream(_SIDE)
+        t.enc.record_stream(_side())
     for l, ly in enumerate(dec.decoder_layers):
         c = Tape()
         sd = seed + (3 * l + 1) * _SITE
@@ -158,7 +163,7 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
             # for every position, whatever the query (reference transformer.py:13-22 with Tk = 1)
             if pre_cc is not None:
                 if l == 0:
-                    torch.cuda.current_stream().wait_stream(_SIDE)
+                    torch.cuda.current_stream().wait_stream(_side())
                 c.v2, c.cc = pre_cc[l]                                                 # [B,E] each
                 c.cc.record_stream(torch.cuda.current_stream())
             else:
@@ -221,7 +226,7 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
                 d_cc = ops.group_sum(d_a2, T) if rg is None else ops.group_sum_segments(d_a2, rg.seq_off, B)   # [B,E]
                 d_v2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_cc, c.v2, bias_done=True)
                 _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, d_v2, t.enc, need_dx=need_denc, accum=denc)
-            side = _SIDE
+            side = _side()
             if side is not None:
                 # nothing on the main chain needs these B-row contractions: the whole sub-chain goes to the side stream
                 side.wait_stream(torch.cuda.current_stream())
@@ -270,7 +275,7 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
     ops.embed_bwd(t.ids.view(-1) if rg is None else t.ids_c, dx,
                   _new(grads, "decoder_embedding.weight", dec.decoder_embedding.weight), rows_dev=rows)
     if side_used and need_denc:
-        torch.cuda.current_stream().wait_stream(_SIDE)        # denc was accumulated on the side stream
+        torch.cuda.current_stream().wait_stream(_side())        # denc was accumulated on the side stream
     return denc.view(B, S, E) if need_denc else None
 
 
