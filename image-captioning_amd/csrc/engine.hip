@@ -136,33 +136,45 @@ __global__ __launch_bounds__(256) void additive_attention_kernel(const float* __
 constexpr int BEAM_MAX_W = 8;
 
 // One wavefront per hypothesis row: log-sum-exp of the row and its W largest logits (ties: lowest id first, as
-// torch.topk returns them on the CPU), written as log-probabilities.
+// torch.topk returns them on the CPU), written as log-probabilities.  CAP = capacity of a lane's sorted list (W <= CAP);
+// the row is swept with 16-byte loads when it is aligned for them.
+template <int CAP, bool VEC>
 __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ logits, int64_t ld, int N, int V, int W,
                                                         float* __restrict__ top_lp, int32_t* __restrict__ top_id) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= N) return;
     const float* lr = logits + (int64_t)row * ld;
-    float bv[BEAM_MAX_W];
-    int bi[BEAM_MAX_W];
+    float bv[CAP];
+    int bi[CAP];
 #pragma unroll
-    for (int k = 0; k < BEAM_MAX_W; ++k) { bv[k] = -INFINITY; bi[k] = INT_MAX; }
+    for (int k = 0; k < CAP; ++k) { bv[k] = -INFINITY; bi[k] = INT_MAX; }
     float mx = -INFINITY, sm = 0.f;
-    for (int c = lane; c < V; c += 64) {
-        const float v = lr[c];
+    // (ids reach a lane in rising order, so a strict compare keeps the lowest id first among equals)
+    auto take = [&](float v, int c) {
         if (v > mx) { sm *= __expf(mx - v); mx = v; }
         sm += __expf(v - mx);
-        // insert (v, c) into this lane's sorted list (ids rise with c, so a strict compare keeps the lowest id first)
+        if (!(v > bv[CAP - 1])) return;        // not among this lane's best CAP: the common case
         float cv = v;
         int ci = c;
 #pragma unroll
-        for (int k = 0; k < BEAM_MAX_W; ++k) {
-            if (k < W && cv > bv[k]) {
+        for (int k = 0; k < CAP; ++k) {
+            if (cv > bv[k]) {
                 const float tv = bv[k]; const int ti = bi[k];
                 bv[k] = cv; bi[k] = ci;
                 cv = tv; ci = ti;
             }
         }
+    };
+    if (VEC) {
+        const f32x4* l4 = reinterpret_cast<const f32x4*>(lr);
+        for (int c = lane; c < V / 4; c += 64) {
+            const f32x4 v = l4[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) take(v[e], 4 * c + e);
+        }
+    } else {
+        for (int c = lane; c < V; c += 64) take(lr[c], c);
     }
     const float wm = wave_max(mx);
     sm = wave_sum(mx > -INFINITY ? sm * __expf(mx - wm) : 0.f);
@@ -173,8 +185,8 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
         wave_argmax(v, i);                      // best remaining head over the wave
         if (bi[0] == i) {                       // the owning lane pops it
 #pragma unroll
-            for (int q = 0; q + 1 < BEAM_MAX_W; ++q) { bv[q] = bv[q + 1]; bi[q] = bi[q + 1]; }
-            bv[BEAM_MAX_W - 1] = -INFINITY; bi[BEAM_MAX_W - 1] = INT_MAX;
+            for (int q = 0; q + 1 < CAP; ++q) { bv[q] = bv[q + 1]; bi[q] = bi[q + 1]; }
+            bv[CAP - 1] = -INFINITY; bi[CAP - 1] = INT_MAX;
         }
         if (lane == 0) {
             top_lp[(int64_t)row * W + k] = v - lse;
@@ -818,8 +830,18 @@ static void carve_beam_bufs(Carver& c, int N, int W, int V, int max_len, BeamBuf
 static int beam_pick(const BeamBufs& d, int t, int B, int W, int V, int eos, int64_t ldtok, int32_t* n_unfinished,
                      hipStream_t s, int32_t* pad_seen = nullptr) {
     const int N = B * W;
-    hipLaunchKernelGGL(beam_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d.logits, (int64_t)V, N, V, W, d.top_lp,
-                       d.top_id);
+    const bool vec = V % 4 == 0 && capdec_aligned16(d.logits);
+#define CAPDEC_TOPK(CAP_)                                                                                               \
+    do {                                                                                                                \
+        if (vec) hipLaunchKernelGGL((beam_topk_kernel<CAP_, true>), dim3((N + 3) / 4), dim3(256), 0, s, d.logits,       \
+                                    (int64_t)V, N, V, W, d.top_lp, d.top_id);                                           \
+        else hipLaunchKernelGGL((beam_topk_kernel<CAP_, false>), dim3((N + 3) / 4), dim3(256), 0, s, d.logits,          \
+                                (int64_t)V, N, V, W, d.top_lp, d.top_id);                                               \
+    } while (0)
+    if (W <= 2) CAPDEC_TOPK(2);
+    else if (W <= 4) CAPDEC_TOPK(4);
+    else CAPDEC_TOPK(BEAM_MAX_W);
+#undef CAPDEC_TOPK
     CAPDEC_LAUNCH_CHECK();
     if (hipMemsetAsync(n_unfinished, 0, sizeof(int32_t), s) != hipSuccess) return (int)hipGetLastError();
     hipLaunchKernelGGL(beam_select_kernel, dim3((B + 63) / 64), dim3(64), 0, s, t, B, W, eos, d.st[t & 1],
