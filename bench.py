@@ -300,12 +300,14 @@ def main():
     else:
         feats = torch.rand(B * S, D, generator=g).to(device)      # one 2048-vector per grid cell
     probe = engine.VocabProbe(LEN)
+    ref = engine.TfModelRef(model)            # the parameter struct of the C call, built once as a serving loop would
 
     def step(use_probe):
         with torch.no_grad():
             enc = model.encode_features(feats).view(B, S, E)
-            ids, lens, n_dirty = engine.tf_greedy_ids(model, enc, LEN, 1, 2, probe=probe if use_probe else None,
-                                                      to_cpu=False)
+            # one GPU: ids, lengths and flags come to the host in one copy; several: they stay on the device for the gather
+            ids, lens, n_dirty = engine.tf_greedy_ids(ref, enc, LEN, 1, 2, probe=probe if use_probe else None,
+                                                      to_cpu=world == 1)
             if world > 1:
                 # batch-sharded decode: the only exchange is the final gather of the token ids
                 if rehearsal:                       # gloo gathers host tensors only
@@ -317,7 +319,7 @@ def main():
                 dist.gather(lens, list(all_len.chunk(world)) if rank == 0 else None, dst=0)
                 if rank == 0:
                     ids, lens = all_ids, all_len
-            if rank == 0:
+            if rank == 0 and world > 1:
                 ids, lens = ids.cpu(), lens.cpu()
         return ids, lens, n_dirty
 

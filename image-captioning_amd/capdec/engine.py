@@ -100,20 +100,31 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
         raise RuntimeError("capdec: enc must be an fp32 tensor on the GPU (HIP); there is no CPU path")
     enc = enc.contiguous()
     B, S, E = enc.shape
-    ref = TfModelRef(dec)
+    ref = dec if isinstance(dec, TfModelRef) else TfModelRef(dec)     # a serving loop builds the struct once
     if E != ref.E:
         raise RuntimeError(f"capdec: encoder width {E} != embed size {ref.E}")
     dev = enc.device
-    out_ids = torch.empty((B, max_length), dtype=torch.int64, device=dev)
-    out_len = torch.empty((B,), dtype=torch.int32, device=dev)
+    # ids, lengths and the dirty flags share one allocation, so that one copy brings all three to the host
+    n_ids = 2 * B * max_length                                   # int64 ids counted in int32 words
+    pack = torch.empty((n_ids + 2 * B,), dtype=torch.int32, device=dev)
+    out_ids = pack[:n_ids].view(torch.int64).view(B, max_length)
+    out_len = pack[n_ids:n_ids + B]
+    dirty = pack[n_ids + B:]
+
+    def to_host():
+        host = torch.empty(pack.shape, dtype=torch.int32, pin_memory=True)
+        host.copy_(pack, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        return host[:n_ids].view(torch.int64).view(B, max_length), host[n_ids:n_ids + B], host[n_ids + B:]
+
     n_dirty = 0
+    host = None
     if B > 0:
         with torch.cuda.device(dev):
             if exact:
                 _exact(lib, ref, enc, max_length, sos, eos, out_ids, out_len)
                 n_dirty = B
             else:
-                dirty = torch.empty((B,), dtype=torch.int32, device=dev)
                 nbytes = lib.capdec_tf_decode_workspace_bytes(ctypes.byref(ref.c), B, S, max_length, extra_cap)
                 if nbytes == 0:
                     raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
@@ -125,7 +136,12 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
                                                        ctypes.byref(probe.c) if probe else None, _stream()),
                            "capdec_tf_greedy_decode")
                 if resolve_dirty:
-                    rows = torch.nonzero(dirty.cpu(), as_tuple=False).flatten()   # the one host sync of the decode
+                    # the one host sync of the decode
+                    if to_cpu:
+                        host = to_host()
+                        rows = torch.nonzero(host[2], as_tuple=False).flatten()
+                    else:
+                        rows = torch.nonzero(dirty.cpu(), as_tuple=False).flatten()
                     n_dirty = int(rows.numel())
                     if n_dirty:
                         # samples whose <PAD>-induced re-run rows did not fit the step's row list (see capdec.h):
@@ -137,8 +153,12 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
                         _exact(lib, ref, sub, max_length, sos, eos, ids2, len2)
                         out_ids.index_copy_(0, rows, ids2)
                         out_len.index_copy_(0, rows, len2)
+                        host = None
     if to_cpu:
-        return out_ids.cpu(), out_len.cpu(), n_dirty
+        if host is None:
+            with torch.cuda.device(dev):
+                host = to_host()
+        return host[0], host[1], n_dirty
     return out_ids, out_len, n_dirty
 
 
