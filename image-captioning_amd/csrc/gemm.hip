@@ -505,14 +505,37 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
     const int per = (nk + args.nsplit - 1) / args.nsplit;
     const int kt0 = split * per, kt1 = min(nk, kt0 + per);
     f32x16 acc[WI][WJ];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = WM == 2 ? (wave >> 1) & 1 : 0, wj = wave & 1, r = lane & 31, h = lane >> 5;
+    const bool relu = (args.flags & CAPDEC_GEMM_RELU) != 0;
+    const bool atomic = (args.flags & CAPDEC_GEMM_ATOMIC) != 0;
+    // One-tile wavefronts fetch their residual values before the contraction, so that the loads' latency is not paid
+    // after it (short contractions: the decode step's projections).  Each element is read by the thread that stores
+    // it, so R may be C itself.
+    constexpr bool RPRE = (WI * WJ == 1);
+    float rpre[RPRE ? 16 : 1];
+    int cpre[RPRE ? 16 : 1];
+    if (RPRE && threadIdx.x < 128 * WM) {
+        const int j = j0 + wj * 32 + r;
+        if (g.R && !atomic) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = i0 + wi * 32 + acc_row(e, h);
+                rpre[e] = (i < nI && j < g.J) ? g.R[(int64_t)i * g.ldri + (int64_t)j * g.ldrj] : 0.f;
+            }
+        }
+        if (g.c_rows) {      // the same for the row map of scattered outputs
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = i0 + wi * 32 + acc_row(e, h);
+                cpre[e] = (i < nI) ? g.c_rows[i] : 0;
+            }
+        }
+    }
     if (DMA) mainloop_dma<WM, WI, WJ, BK, dma_cut<BK, KG>(), dma_nbuf<KG>(), TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, nI, g.J, i0, j0, kt0, kt1, lds, acc);
     else mainloop<WM, WI, WJ, BK, VEC, TP, TQ, KG>(g.P, g.Q, g.ldp, g.ldq, nI, g.J, K, i0, j0, kt0, kt1, lds, acc);
     if (KG > 1 && threadIdx.x >= 128 * WM) return;   // group 0 holds the summed tile
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wi = WM == 2 ? wave >> 1 : 0, wj = wave & 1, r = lane & 31, h = lane >> 5;
-    const bool relu = (args.flags & CAPDEC_GEMM_RELU) != 0;
-    const bool atomic = (args.flags & CAPDEC_GEMM_ATOMIC) != 0;
     const capdec_gemm_extra& x = args.x;
 #pragma unroll
     for (int tj = 0; tj < WJ; ++tj) {
@@ -528,7 +551,7 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
                 const int i = i0 + wi * 32 * WI + ti * 32 + acc_row(e, h);
                 if (i >= nI) continue;
                 // c_rows: output row i is stored at row c_rows[i] (k/v of a decode step go straight to their cache rows)
-                const int64_t ci = g.c_rows ? (int64_t)g.c_rows[i] : (int64_t)i;
+                const int64_t ci = g.c_rows ? (int64_t)(RPRE ? cpre[RPRE ? e : 0] : g.c_rows[i]) : (int64_t)i;
                 float* c = &g.C[ci * g.ldci + (int64_t)j * g.ldcj];
                 if (atomic) {
                     // C += partial; the affine terms (bias, BatchNorm shift) enter once, with the first k-range
@@ -551,7 +574,7 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
                     v = (tg == x.ignore_index) ? 0.f : (expf(v - x.lse[i]) - (tg == (int64_t)j ? 1.f : 0.f)) * x.gscale[0];
                 }
                 if (x.mask && !(x.mask[(int64_t)i * x.ldm + j] > 0.f)) v = 0.f;
-                if (g.R) v += g.R[(int64_t)i * g.ldri + (int64_t)j * g.ldrj];
+                if (g.R) v += RPRE ? rpre[RPRE ? e : 0] : g.R[(int64_t)i * g.ldri + (int64_t)j * g.ldrj];
                 *c = v;
             }
         }
@@ -773,25 +796,29 @@ int launch_gemm_cfg(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hip
 }
 
 // Tile choice.  cfg = 0: automatic; otherwise force: 11 / 116 = 64x64 (BK 32 / 16), 22 / 216 = 128x128 (BK 32 / 16),
-// 32 = 32x64 tile with the k-loop split over the workgroup's two wave pairs.
+// 32 / 316 = 32x64 tile with the k-loop split over the workgroup's two wave pairs (BK 32 / 16).
 int g_force_cfg = 0;
 
 template <bool TP, bool TQ>
 int launch_gemm_layout(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hipStream_t s) {
     int cfg = g_force_cfg;
     if (cfg == 0) {
-        // Measured on MI355X at the decoder's shapes: 64x64 tiles at BK 16 (20 KiB of LDS, so every tile of a
-        // 1280-tile grid is resident at once and nothing runs as a lone tail) win wherever there is at least one
-        // tile per CU; below that, halving the tile lets twice as many CUs share the MFMA work.  Split-K weight
-        // gradients keep BK 32 (their k loop is long), and 128x128 tiles pay off only for very large outputs.
+        // Measured on MI355X at the decoder's shapes (dependent chains of 512-deep contractions).  From about four
+        // 64x64 tiles per CU on, those tiles at BK 16 win (20 KiB of LDS: every tile of a 1280-tile grid is resident at
+        // once and nothing runs as a lone tail); between two and four per CU the deeper k-tile does.  Below that the
+        // chip is not full: a 32x64 tile whose k-loop is split over two wave pairs spreads the MFMA work over twice as
+        // many SIMDs, at BK 32 when every workgroup has a CU to itself, at BK 16 (37 KiB of LDS, four workgroups per
+        // CU) when some CUs hold several.  Split-K weight gradients keep BK 32 (their k loop is long), and 128x128
+        // tiles pay off only for very large outputs.
         const long tiles64 = (long)((maxI + 63) / 64) * ((maxJ + 63) / 64) * ngroups;
         const bool atomic = (a.flags & CAPDEC_GEMM_ATOMIC) != 0;
         if (atomic) cfg = tiles64 >= 1024 ? 216 : 11;
-        else cfg = tiles64 < 256 ? 32 : 116;
+        else cfg = tiles64 <= 160 ? 32 : (tiles64 < 512 ? 316 : (tiles64 < 1024 ? 11 : 116));
     }
     if (cfg == 22) return launch_gemm_cfg<2, 2, 2, 32, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
     if (cfg == 216) return launch_gemm_cfg<2, 2, 2, 16, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
     if (cfg == 32) return launch_gemm_cfg<1, 1, 1, 32, TP, TQ, 2>(a, ngroups, maxI, maxJ, vec, s);
+    if (cfg == 316) return launch_gemm_cfg<1, 1, 1, 16, TP, TQ, 2>(a, ngroups, maxI, maxJ, vec, s);
     if (cfg == 116) return launch_gemm_cfg<2, 1, 1, 16, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
     return launch_gemm_cfg<2, 1, 1, 32, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
 }
@@ -842,7 +869,7 @@ int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int 
 extern "C" {
 
 int capdec_gemm_force_config(int cfg) {
-    CAPDEC_REQUIRE(cfg == 0 || cfg == 11 || cfg == 22 || cfg == 216 || cfg == 32 || cfg == 116);
+    CAPDEC_REQUIRE(cfg == 0 || cfg == 11 || cfg == 22 || cfg == 216 || cfg == 32 || cfg == 116 || cfg == 316);
     g_force_cfg = cfg;
     return 0;
 }

@@ -85,7 +85,8 @@ typedef struct capdec_gemm_extra {
                                   zeros) from k_dev[0] up to the next multiple of 32 */
 } capdec_gemm_extra;
 /* Tuning hook for benchmarks: 0 = automatic tile choice, 11 / 116 = 64x64 (BK 32 / 16), 22 / 216 = 128x128 (BK 32 / 16),
- * 32 = 32x64 tile with its k-loop split over the two wave pairs.  Process-wide; not for production use. */
+ * 32 / 316 = 32x64 tile with its k-loop split over the two wave pairs (BK 32 / 16).  Process-wide; not for production
+ * use. */
 int capdec_gemm_force_config(int cfg);
 /* Tuning hook for benchmarks: 0 = automatic, 1 = operand tiles always staged through registers (never loaded straight
  * into LDS).  Process-wide; not for production use. */
