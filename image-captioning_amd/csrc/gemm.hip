@@ -546,36 +546,83 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
         const float sh = g.shift_j ? g.shift_j[j] : 0.f;
 #pragma unroll
         for (int ti = 0; ti < WI; ++ti) {
+            // Large tiles make two passes over the 16 registers: every load of the epilogue first, then the stores.
+            // Interleaved, each load has to wait for the store before it (the compiler cannot know that C and the
+            // epilogue's operands do not overlap), one memory round trip per register.  One-tile wavefronts keep the
+            // interleaved form, which needs fewer registers (their occupancy matters more), with the residual and the
+            // row map already in registers.
+            if constexpr (WI * WJ < 4) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = i0 + wi * 32 * WI + ti * 32 + acc_row(e, h);
-                if (i >= nI) continue;
-                // c_rows: output row i is stored at row c_rows[i] (k/v of a decode step go straight to their cache rows)
-                const int64_t ci = g.c_rows ? (int64_t)(RPRE ? cpre[RPRE ? e : 0] : g.c_rows[i]) : (int64_t)i;
-                float* c = &g.C[ci * g.ldci + (int64_t)j * g.ldcj];
-                if (atomic) {
-                    // C += partial; the affine terms (bias, BatchNorm shift) enter once, with the first k-range
-                    float v = acc[ti][tj][e];
-                    if (split == 0) {
-                        v += bj;
-                        if (g.bias_i) v += g.bias_i[i];
+                for (int e = 0; e < 16; ++e) {
+                    const int i = i0 + wi * 32 * WI + ti * 32 + acc_row(e, h);
+                    if (i >= nI) continue;
+                    // c_rows: output row i is stored at row c_rows[i] (k/v of a decode step go straight to their cache rows)
+                    const int64_t ci = g.c_rows ? (int64_t)(RPRE ? cpre[RPRE ? e : 0] : g.c_rows[i]) : (int64_t)i;
+                    float* c = &g.C[ci * g.ldci + (int64_t)j * g.ldcj];
+                    if (atomic) {
+                        // C += partial; the affine terms (bias, BatchNorm shift) enter once, with the first k-range
+                        float v = acc[ti][tj][e];
+                        if (split == 0) {
+                            v += bj;
+                            if (g.bias_i) v += g.bias_i[i];
+                        }
+                        if (g.scale_j) v = v * sc + (split == 0 ? sh : 0.f);
+                        atomicAdd(c, v);
+                        continue;
                     }
-                    if (g.scale_j) v = v * sc + (split == 0 ? sh : 0.f);
-                    atomicAdd(c, v);
-                    continue;
+                    float v = acc[ti][tj][e] + bj;
+                    if (g.bias_i) v += g.bias_i[i];
+                    if (g.scale_j) v = v * sc + sh;
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (x.lse) {
+                        // d(mean NLL)/d(logit): (softmax - onehot) * gscale on rows with a counted target
+                        const int64_t tg = x.tgt[i];
+                        v = (tg == x.ignore_index) ? 0.f : (expf(v - x.lse[i]) - (tg == (int64_t)j ? 1.f : 0.f)) * x.gscale[0];
+                    }
+                    if (x.mask && !(x.mask[(int64_t)i * x.ldm + j] > 0.f)) v = 0.f;
+                    if (g.R) v += RPRE ? rpre[RPRE ? e : 0] : g.R[(int64_t)i * g.ldri + (int64_t)j * g.ldrj];
+                    *c = v;
                 }
-                float v = acc[ti][tj][e] + bj;
-                if (g.bias_i) v += g.bias_i[i];
-                if (g.scale_j) v = v * sc + sh;
-                if (relu) v = fmaxf(v, 0.f);
-                if (x.lse) {
-                    // d(mean NLL)/d(logit): (softmax - onehot) * gscale on rows with a counted target
-                    const int64_t tg = x.tgt[i];
-                    v = (tg == x.ignore_index) ? 0.f : (expf(v - x.lse[i]) - (tg == (int64_t)j ? 1.f : 0.f)) * x.gscale[0];
+            } else {
+                float val[16];
+                int64_t off[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = i0 + wi * 32 * WI + ti * 32 + acc_row(e, h);
+                    off[e] = -1;
+                    if (i >= nI) continue;
+                    const int64_t ci = g.c_rows ? (int64_t)g.c_rows[i] : (int64_t)i;
+                    off[e] = ci * g.ldci + (int64_t)j * g.ldcj;
+                    float v;
+                    if (atomic) {
+                        v = acc[ti][tj][e];
+                        if (split == 0) {
+                            v += bj;
+                            if (g.bias_i) v += g.bias_i[i];
+                        }
+                        if (g.scale_j) v = v * sc + (split == 0 ? sh : 0.f);
+                    } else {
+                        v = acc[ti][tj][e] + bj;
+                        if (g.bias_i) v += g.bias_i[i];
+                        if (g.scale_j) v = v * sc + sh;
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (x.lse) {
+                            const int64_t tg = x.tgt[i];
+                            v = (tg == x.ignore_index)
+                                    ? 0.f
+                                    : (expf(v - x.lse[i]) - (tg == (int64_t)j ? 1.f : 0.f)) * x.gscale[0];
+                        }
+                        if (x.mask && !(x.mask[(int64_t)i * x.ldm + j] > 0.f)) v = 0.f;
+                        if (g.R) v += g.R[(int64_t)i * g.ldri + (int64_t)j * g.ldrj];
+                    }
+                    val[e] = v;
                 }
-                if (x.mask && !(x.mask[(int64_t)i * x.ldm + j] > 0.f)) v = 0.f;
-                if (g.R) v += RPRE ? rpre[RPRE ? e : 0] : g.R[(int64_t)i * g.ldri + (int64_t)j * g.ldrj];
-                *c = v;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (off[e] < 0) continue;
+                    if (atomic) atomicAdd(&g.C[off[e]], val[e]);
+                    else g.C[off[e]] = val[e];
+                }
             }
         }
     }
