@@ -52,7 +52,7 @@ def main():
     mfma("gemm_kernel 32x64 (decode projection)", "1024x512x512", 2.0 * M * E * E, lambda: ops.linear(x, W, b, out=out))
     Ws = [rnd(E, E) for _ in range(3)]
     outs = [torch.empty(M, E, device="cuda") for _ in range(3)]
-    mfma("gemm_kernel 64x64 grouped (decode Q,K,V)", "3 x 1024x512x512", 6.0 * M * E * E,
+    mfma("gemm_kernel 32x64 BK16 grouped (decode Q,K,V)", "3 x 1024x512x512", 6.0 * M * E * E,
          lambda: ops.gemm_groups([dict(P=x, Q=w, C=o) for w, o in zip(Ws, outs)], E))
     Wv, bv = rnd(V, E), rnd(V)
     mfma("vocab_reduce_kernel (projection + arg-max)", "1024x10000x512", 2.0 * M * V * E, lambda: ops.vocab_argmax(x, Wv, bv))
