@@ -134,6 +134,13 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     float bias[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = a.b_ih[g * a.Hd + u] + a.b_hh[g * a.Hd + u];
+    // the previous cell state of all 16 rows first: inside the loop each load would wait for the stores before it
+    float cprev[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        cprev[e] = (a.c0 && i < a.B) ? a.c0[(int64_t)i * a.Hd + u] : 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
         const float gi = acc[0][e] + bias[0], gf = acc[1][e] + bias[1];
         const float gg = xch[((wj * 2 + 0) * 16 + e) * 64 + lane] + bias[2];
         const float go = xch[((wj * 2 + 1) * 16 + e) * 64 + lane] + bias[3];
-        const float cp = a.c0 ? a.c0[(int64_t)i * a.Hd + u] : 0.f;
+        const float cp = cprev[e];
         const float cn = sigmoidf_(gf) * cp + sigmoidf_(gi) * tanhf(gg);
         const float hn = sigmoidf_(go) * tanhf(cn);
         a.c1[(int64_t)i * a.Hd + u] = cn;
@@ -267,6 +274,13 @@ __global__ __launch_bounds__(256) void lstm_step_dma_kernel(LstmArgs a) {
     float bias[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = a.b_ih[g * a.Hd + u] + a.b_hh[g * a.Hd + u];
+    // the previous cell state of all 16 rows first: inside the loop each load would wait for the stores before it
+    float cprev[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        cprev[e] = (a.c0 && i < a.B) ? a.c0[(int64_t)i * a.Hd + u] : 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(256) void lstm_step_dma_kernel(LstmArgs a) {
         const float gi = acc[0][e] + bias[0], gf = acc[1][e] + bias[1];
         const float gg = xch[((wj * 2 + 0) * 16 + e) * 64 + lane] + bias[2];
         const float go = xch[((wj * 2 + 1) * 16 + e) * 64 + lane] + bias[3];
-        const float cp = a.c0 ? a.c0[(int64_t)i * a.Hd + u] : 0.f;
+        const float cp = cprev[e];
         const float cn = sigmoidf_(gf) * cp + sigmoidf_(gi) * tanhf(gg);
         const float hn = sigmoidf_(go) * tanhf(cn);
         a.c1[(int64_t)i * a.Hd + u] = cn;
