@@ -65,6 +65,7 @@ _SIGNATURES = {
     "capdec_strerror": (c_char_p, [c_int]),
     "capdec_gemm": (c_int, [POINTER(GemmGroup), c_int, c_int, c_int, _P]),
     "capdec_vocab_tiles": (c_int, [c_int]),
+    "capdec_vocab_partial_elems": (c_size_t, [c_int, c_int]),
     "capdec_vocab_argmax_partial": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "capdec_argmax_finalize": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
     "capdec_vocab_lse_partial": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int, _P, _P, _P]),

@@ -248,8 +248,9 @@ def vocab_argmax(x, W, b):
     M, K = x.shape
     V = W.shape[0]
     nt = lib.capdec_vocab_tiles(V)
-    pv = torch.empty((M, nt), device=x.device, dtype=torch.float32)
-    pi = torch.empty((M, nt), device=x.device, dtype=torch.int32)
+    n = lib.capdec_vocab_partial_elems(M, V)
+    pv = torch.empty((n,), device=x.device, dtype=torch.float32)
+    pi = torch.empty((n,), device=x.device, dtype=torch.int32)
     _lib.check(lib.capdec_vocab_argmax_partial(x.data_ptr(), _row_stride(x, "x"), _chk(W).data_ptr(),
                                                _chk(b).data_ptr(), M, V, K, pv.data_ptr(), pi.data_ptr(), _stream()),
                "capdec_vocab_argmax_partial")
@@ -268,8 +269,9 @@ def vocab_nll(x, W, b, targets, ignore_index=0):
     M, K = x.shape
     V = W.shape[0]
     nt = lib.capdec_vocab_tiles(V)
-    pm = torch.empty((M, nt), device=x.device, dtype=torch.float32)
-    ps = torch.empty((M, nt), device=x.device, dtype=torch.float32)
+    n = lib.capdec_vocab_partial_elems(M, V)
+    pm = torch.empty((n,), device=x.device, dtype=torch.float32)
+    ps = torch.empty((n,), device=x.device, dtype=torch.float32)
     _lib.check(lib.capdec_vocab_lse_partial(x.data_ptr(), _row_stride(x, "x"), _chk(W).data_ptr(), _chk(b).data_ptr(),
                                             M, V, K, pm.data_ptr(), ps.data_ptr(), _stream()),
                "capdec_vocab_lse_partial")

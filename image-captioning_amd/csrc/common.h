@@ -26,6 +26,13 @@
 
 static inline bool capdec_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Per-tile partial results of the fused vocabulary projections: blocks of 64 rows, [row block][vocabulary tile][64],
+// so that the 64 or 128 rows a tile finishes are stored as contiguous runs instead of one 4-byte store per row stride.
+__host__ __device__ inline int64_t capdec_part_off(int row, int tile, int ntiles) {
+    return ((int64_t)(row >> 6) * ntiles + tile) * 64 + (row & 63);
+}
+static inline size_t capdec_part_elems(int M, int ntiles) { return (size_t)((M + 63) / 64) * 64 * (size_t)ntiles; }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

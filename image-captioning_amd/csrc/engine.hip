@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __rest
     if (b >= B) return;
     float v = -INFINITY;
     int i = INT_MAX;
-    for (int n = lane; n < ntiles; n += 64) argmax_merge(v, i, pv[(int64_t)b * ntiles + n], pi[(int64_t)b * ntiles + n]);
+    for (int n = lane; n < ntiles; n += 64) argmax_merge(v, i, pv[capdec_part_off(b, n, ntiles)], pi[capdec_part_off(b, n, ntiles)]);
     wave_argmax(v, i);
     if (i < 0 || i >= V) i = 0;   // all-NaN row: no finite winner
     if (lane == 0) {
@@ -414,8 +414,8 @@ static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, 
     d.cv = c.take<float>((size_t)m->L * BE * S);
     d.cc = c.take<float>((size_t)m->L * BE);
     const size_t nt = (size_t)capdec_vocab_tiles(m->V);
-    d.pval = c.take<float>((size_t)B * nt);
-    d.pidx = c.take<int32_t>((size_t)B * nt);
+    d.pval = c.take<float>(capdec_part_elems(B, (int)nt));
+    d.pidx = c.take<int32_t>(capdec_part_elems(B, (int)nt));
     d.tok = c.take<int32_t>((size_t)B * (max_len + 1));
     d.done = c.take<int32_t>((size_t)B);
     d.first_pad = c.take<int32_t>((size_t)B);
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void cached_advance_kernel(const float* __rest
     if (b >= B) return;
     float v = -INFINITY;
     int i = INT_MAX;
-    for (int n = lane; n < ntiles; n += 64) argmax_merge(v, i, pv[(int64_t)b * ntiles + n], pi[(int64_t)b * ntiles + n]);
+    for (int n = lane; n < ntiles; n += 64) argmax_merge(v, i, pv[capdec_part_off(b, n, ntiles)], pi[capdec_part_off(b, n, ntiles)]);
     wave_argmax(v, i);
     if (i < 0 || i >= V) i = 0;   // all-NaN row: no finite winner
     int p0 = INT_MAX, running = 0, base = 0;
@@ -653,8 +653,8 @@ static size_t carve_full(const capdec_tf_model* m, int B, int S, int T, bool dec
     d.ck = c.take<float>((size_t)m->L * B * S * m->E);
     d.cv = c.take<float>((size_t)m->L * B * S * m->E);
     const size_t nt = (size_t)capdec_vocab_tiles(m->V);
-    d.pval = c.take<float>(decode ? (size_t)B * nt : 1);
-    d.pidx = c.take<int32_t>(decode ? (size_t)B * nt : 1);
+    d.pval = c.take<float>(decode ? capdec_part_elems(B, (int)nt) : 1);
+    d.pidx = c.take<int32_t>(decode ? capdec_part_elems(B, (int)nt) : 1);
     d.tok = c.take<int32_t>((size_t)B * (T + 1));
     d.done = c.take<int32_t>((size_t)B);
     if (w) *w = d;
@@ -752,8 +752,8 @@ static size_t carve_rnn(const capdec_rnn_model* m, int B, int max_len, void* bas
         d.c[n] = c.take<float>((size_t)B * m->Hd);
     }
     const size_t nt = (size_t)capdec_vocab_tiles(m->V);
-    d.pval = c.take<float>((size_t)B * nt);
-    d.pidx = c.take<int32_t>((size_t)B * nt);
+    d.pval = c.take<float>(capdec_part_elems(B, (int)nt));
+    d.pidx = c.take<int32_t>(capdec_part_elems(B, (int)nt));
     d.tok = c.take<int32_t>((size_t)B * (max_len + 1));
     d.done = c.take<int32_t>((size_t)B);
     if (w) *w = d;
@@ -1133,8 +1133,8 @@ static size_t carve_satt(const capdec_satt_model* m, int B, int max_len, void* b
         d.c[n] = c.take<float>((size_t)B * m->Hd);
     }
     const size_t nt = (size_t)capdec_vocab_tiles(m->V);
-    d.pval = c.take<float>((size_t)B * nt);
-    d.pidx = c.take<int32_t>((size_t)B * nt);
+    d.pval = c.take<float>(capdec_part_elems(B, (int)nt));
+    d.pidx = c.take<int32_t>(capdec_part_elems(B, (int)nt));
     d.tok = c.take<int32_t>((size_t)B * (max_len + 1));
     d.done = c.take<int32_t>((size_t)B);
     if (w) *w = d;

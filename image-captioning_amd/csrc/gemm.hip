@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256, 5) void vocab_reduce_kernel(const float* __res
     const int t = threadIdx.x;
     if (t < BJ && j0 + t < M) {
         float a0 = sm_a[t], a1 = sm_a[BJ + t];
-        const int64_t o = (int64_t)(j0 + t) * ntiles + tile_i;
+        const int64_t o = capdec_part_off(j0 + t, tile_i, ntiles);
         if (MODE == 0) {
             int b0 = reinterpret_cast<int*>(sm_b)[t], b1 = reinterpret_cast<int*>(sm_b)[BJ + t];
             argmax_merge(a0, b0, a1, b1);
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void argmax_finalize_kernel(const float* __res
     if (row >= M) return;
     float v = -INFINITY;
     int i = INT_MAX;
-    for (int t = lane; t < ntiles; t += 64) argmax_merge(v, i, pv[(int64_t)row * ntiles + t], pi[(int64_t)row * ntiles + t]);
+    for (int t = lane; t < ntiles; t += 64) argmax_merge(v, i, pv[capdec_part_off(row, t, ntiles)], pi[capdec_part_off(row, t, ntiles)]);
     wave_argmax(v, i);
     if (lane == 0) {
         out_idx[row] = i;
@@ -759,12 +759,12 @@ __global__ __launch_bounds__(256) void nll_finalize_kernel(const float* __restri
         const int row = blockIdx.x * NLL_ROWS + rr;
         if (row >= M) break;
         float mx = -INFINITY;
-        for (int t = lane; t < ntiles; t += 64) mx = fmaxf(mx, pm[(int64_t)row * ntiles + t]);
+        for (int t = lane; t < ntiles; t += 64) mx = fmaxf(mx, pm[capdec_part_off(row, t, ntiles)]);
         mx = wave_max(mx);
         float s = 0.f;
         for (int t = lane; t < ntiles; t += 64) {
-            const float m = pm[(int64_t)row * ntiles + t];
-            if (m > -INFINITY) s += ps[(int64_t)row * ntiles + t] * expf(m - mx);
+            const float m = pm[capdec_part_off(row, t, ntiles)];
+            if (m > -INFINITY) s += ps[capdec_part_off(row, t, ntiles)] * expf(m - mx);
         }
         s = wave_sum(s);
         const float lse = mx + logf(s);
@@ -937,6 +937,7 @@ int capdec_gemm_ex(const capdec_gemm_group* groups, int ngroups, int K, int flag
 }
 
 int capdec_vocab_tiles(int V) { return (V + VOCAB_BI - 1) / VOCAB_BI; }
+size_t capdec_vocab_partial_elems(int M, int V) { return (M < 0 || V < 1) ? 0 : capdec_part_elems(M, capdec_vocab_tiles(V)); }
 
 static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const float* W, const float* bias, int M, int V,
                                int K, float* out_a, void* out_b, hipStream_t s) {

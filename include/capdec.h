@@ -98,9 +98,12 @@ int capdec_gemm_ex(const capdec_gemm_group* groups /*host*/, int ngroups, int K,
  *   replaces fc2 + argmax, transformer.py:137,155 and cnnrnn_model.py:84-90 (log_softmax is
  *   monotone, so the arg-max of the logits is the arg-max of the log-probabilities).
  * x [M,K] (row stride ldx), W [V,K], bias [V].  Writes per-row partial winners for each vocabulary
- * tile into part_val/part_idx [M, ntiles]; ntiles = capdec_vocab_tiles(V).  Ties resolve to the
- * lowest index, as torch.argmax does.  Finish with capdec_argmax_finalize / capdec_greedy_advance. */
+ * tile into part_val/part_idx: capdec_vocab_partial_elems(M, V) elements each (blocks of 64 rows,
+ * [row block][tile][64], ntiles = capdec_vocab_tiles(V) tiles; opaque to the caller, read back by the
+ * finalize / advance calls).  Ties resolve to the lowest index, as torch.argmax does.  Finish with
+ * capdec_argmax_finalize / capdec_greedy_advance. */
 int capdec_vocab_tiles(int V);
+size_t capdec_vocab_partial_elems(int M, int V);
 int capdec_vocab_argmax_partial(const float* x, int64_t ldx, const float* W, const float* bias, int M, int V,
                                 int K, float* part_val, int32_t* part_idx, void* stream);
 int capdec_argmax_finalize(const float* part_val, const int32_t* part_idx, int M, int ntiles,
@@ -110,7 +113,7 @@ int capdec_argmax_finalize(const float* part_val, const int32_t* part_idx, int M
  *   replaces fc2 + criterion, transformer.py:137 + train.py:216,254-256.
  * Writes per-row lse[M] and picked target logit tgt_logit[M]; rows whose target == ignore_index
  * get nll contribution 0.  loss_sum[0] += sum nll, loss_sum[1] += number of valid rows (both must be
- * zeroed by the caller).  part_* are scratch [M, ntiles] floats. */
+ * zeroed by the caller).  part_* are scratch of capdec_vocab_partial_elems(M, V) floats each. */
 int capdec_vocab_lse_partial(const float* x, int64_t ldx, const float* W, const float* bias, int M, int V, int K,
                              float* part_max, float* part_sum, void* stream);
 int capdec_nll_finalize(const float* part_max, const float* part_sum, int M, int ntiles, const float* x,

@@ -31,6 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.capdec_abi_version() == _lib.ABI_VERSION
     assert lib.capdec_strerror(-22).decode().startswith("capdec")
     assert lib.capdec_vocab_tiles(10000) == 157
+    assert lib.capdec_vocab_partial_elems(1000, 10000) == 1024 * 157      # rows in blocks of 64
 
 
 def test_argument_validation_without_gpu():
