@@ -414,7 +414,7 @@ def test_gemm_split_k_atomic_and_forced_tiles(ops):
     b, sc, sh = torch.randn(80, generator=g), torch.rand(80, generator=g) + 0.5, torch.randn(80, generator=g)
     ref = (x.double() @ W.double().t() + b.double()) * sc.double() + sh.double()
     try:
-        for cfg in (0, 11, 116, 32, 22, 216):
+        for cfg in (0, 11, 116, 32, 316, 22, 216):
             lib.capdec_gemm_force_config(cfg)
             y = ops.linear(x.cuda(), W.cuda(), b.cuda(), scale=sc.cuda(), shift=sh.cuda(), split_k=True)
             close(y, ref, what=f"split-k cfg {cfg}")
@@ -439,7 +439,7 @@ def test_gemm_tiles_loaded_straight_into_lds(ops):
     dy, xx = torch.randn(352, 72, generator=g), torch.randn(352, 132, generator=g)
     dy2, Wd = torch.randn(300, 96, generator=g), torch.randn(96, 132, generator=g)
     try:
-        for cfg in (0, 11, 116, 32, 22, 216):
+        for cfg in (0, 11, 116, 32, 316, 22, 216):
             lib.capdec_gemm_force_config(cfg)
             outs = []
             for staging in (1, 0):
@@ -466,7 +466,7 @@ def test_gemm_direct_to_lds_edge_shapes_and_device_limits(ops):
     lib = _lib.load()
     g = torch.Generator().manual_seed(79)
     try:
-        for cfg in (0, 11, 116, 32, 216):
+        for cfg in (0, 11, 116, 32, 316, 216):
             lib.capdec_gemm_force_config(cfg)
             for (M, N, K) in [(1, 4, 16), (3, 8, 32), (65, 68, 48), (130, 260, 64)]:
                 x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
@@ -488,6 +488,43 @@ def test_gemm_direct_to_lds_edge_shapes_and_device_limits(ops):
                 close(dw, dy[:live].double().t() @ xx[:live].double(), atol=1e-6, what=f"cfg {cfg} k limit {live}")
     finally:
         lib.capdec_gemm_force_config(0)
+
+
+def test_gemm_epilogue_residual_accumulate_and_mask_in_every_tile(ops):
+    """Epilogue operands that some tile configurations fetch before the contraction and others in a pass of their own:
+    residual, in-place accumulation (R == C), ReLU mask, with and without a device-side row limit."""
+    from capdec import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(80)
+    M, N, K = 200, 136, 96
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    dy, Wd = torch.randn(M, N, generator=g), torch.randn(N, K, generator=g)
+    mask = (torch.rand(M, K, generator=g) > 0.4).float()
+    acc0 = torch.randn(M, K, generator=g)
+    try:
+        for cfg in (0, 11, 116, 32, 316, 22, 216):
+            lib.capdec_gemm_force_config(cfg)
+            for staging in (1, 0):
+                lib.capdec_gemm_force_staging(staging)
+                tag = f"cfg {cfg} staging {staging}"
+                y = ops.linear(x.cuda(), W.cuda(), b.cuda(), residual=R.cuda())
+                close(y, x.double() @ W.double().t() + b.double() + R.double(), what=f"residual {tag}")
+                for live in (0, 33, 200):
+                    rows = torch.tensor([live], dtype=torch.int32, device="cuda")
+                    out = torch.full((M, N), 7.0, device="cuda")
+                    ops.linear(x.cuda(), W.cuda(), b.cuda(), residual=R.cuda(), out=out, rows_dev=rows)
+                    close(out[:live], (x.double() @ W.double().t() + b.double() + R.double())[:live],
+                          what=f"residual rows {live} {tag}")
+                    assert bool((out[live:] == 7.0).all()), f"{tag}: rows past the limit were written"
+                dx = ops.linear_dgrad(dy.cuda(), Wd.cuda(), mask=mask.cuda())
+                close(dx, (dy.double() @ Wd.double()) * mask.double(), what=f"masked dgrad {tag}")
+                acc = acc0.clone().cuda()
+                ops.linear_dgrad(dy.cuda(), Wd.cuda(), accum=acc)
+                close(acc, dy.double() @ Wd.double() + acc0.double(), what=f"accumulating dgrad {tag}")
+    finally:
+        lib.capdec_gemm_force_config(0)
+        lib.capdec_gemm_force_staging(0)
 
 
 def test_maximum_length_50_forward_greedy_and_beam():
