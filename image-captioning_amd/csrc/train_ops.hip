@@ -904,15 +904,26 @@ __global__ __launch_bounds__(256) void softmax_nll_grad_kernel(float* __restrict
         }
         float mx = -INFINITY, sm = 0.f;
         if (VEC) {
+            // four independent 16-byte loads in flight per lane
             const f32x4* l4 = reinterpret_cast<const f32x4*>(lr);
-            for (int c = lane; c < V / 4; c += 64) {
-                const f32x4 v = l4[c];
-                const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            const int n4 = V / 4;
+            for (int c0 = lane; c0 < n4; c0 += 256) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + 64 * u;
+                    v[u] = c < n4 ? l4[c] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                }
+                float m4 = mx;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m4 = fmaxf(m4, fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));
                 if (m4 > mx) {
                     sm *= __expf(mx - m4);
                     mx = m4;
                 }
-                sm += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    sm += __expf(v[u][0] - mx) + __expf(v[u][1] - mx) + __expf(v[u][2] - mx) + __expf(v[u][3] - mx);
             }
         } else {
             for (int c = lane; c < V; c += 64) {
@@ -936,12 +947,23 @@ __global__ __launch_bounds__(256) void softmax_nll_grad_kernel(float* __restrict
         if (lane == 0 && lse_out) lse_out[row] = lse;
         if (VEC) {
             f32x4* l4 = reinterpret_cast<f32x4*>(lr);
-            for (int c = lane; c < V / 4; c += 64) {
-                f32x4 v = l4[c];
+            const int n4 = V / 4;
+            for (int c0 = lane; c0 < n4; c0 += 256) {
+                f32x4 v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    v[k] = counted ? (__expf(v[k] - lse) - ((int64_t)(4 * c + k) == tg ? 1.f : 0.f)) * gs : 0.f;
-                l4[c] = v;
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + 64 * u;
+                    if (c < n4) v[u] = l4[c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + 64 * u;
+                    if (c >= n4) continue;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        v[u][k] = counted ? (__expf(v[u][k] - lse) - ((int64_t)(4 * c + k) == tg ? 1.f : 0.f)) * gs : 0.f;
+                    l4[c] = v[u];
+                }
             }
         } else {
             for (int c = lane; c < V; c += 64)
