@@ -979,6 +979,81 @@ __global__ __launch_bounds__(256) void softmax_nll_grad_kernel(float* __restrict
 }
 
 
+// The same for rows of at most 256 * NV4 logits: the whole row sits in the wavefront's registers (4 * NV4 per lane), so
+// it is read from memory once -- re-read in a second pass, a 40 KB row has long left the L2 that 32 CUs share.  Buffer
+// addressing (one lane offset in a VGPR, the vector's offset in an SGPR) keeps the NV4 loads and stores from each
+// holding an address register pair; loads past the row's end return zeros and stores there are dropped.
+typedef int capdec_i32x4 __attribute__((ext_vector_type(4)));
+
+template <int NV4>
+__global__ __launch_bounds__(256, 2) void softmax_nll_grad_reg_kernel(float* __restrict__ logits, int64_t ld,
+                                                                      const int64_t* __restrict__ targets, int M, int V,
+                                                                      int64_t ignore_index, float* __restrict__ gscale,
+                                                                      float* __restrict__ sums,
+                                                                      float* __restrict__ lse_out,
+                                                                      const int32_t* __restrict__ rows_dev) {
+    __shared__ float red[4];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const float gs = 1.0f / sums[1];            // complete: the counting kernel ran before this one
+    if (blockIdx.x == 0 && threadIdx.x == 0) gscale[0] = gs;
+    const int live = rows_dev ? min(M, rows_dev[0]) : M;
+    const int upto = rows_dev ? min(M, (live + 31) / 32 * 32) : M;
+    const int n4 = V / 4;
+    float acc = 0.f;
+#pragma unroll 1
+    for (int rr = wave; rr < SM_ROWS; rr += 4) {
+        const int row = blockIdx.x * SM_ROWS + rr;
+        if (row >= upto) break;
+        float* lr = logits + (int64_t)row * ld;
+        const int64_t tg = row < live ? targets[row] : ignore_index;
+        const bool counted = tg != ignore_index;
+        if (row >= live || (!lse_out && !counted)) {
+            f32x4* l4 = reinterpret_cast<f32x4*>(lr);
+            for (int c = lane; c < n4; c += 64) l4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(lr, 0, V * 4, 0x00020000);
+        f32x4 v[NV4];
+#pragma unroll
+        for (int u = 0; u < NV4; ++u) {
+            v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, u * 1024, 0));
+            if (lane + 64 * u >= n4) v[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+        const float tl = counted ? lr[tg] : 0.f;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < NV4; ++u) mx = fmaxf(mx, fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));
+        mx = wave_max(mx);
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV4; ++u)
+            sm += __expf(v[u][0] - mx) + __expf(v[u][1] - mx) + __expf(v[u][2] - mx) + __expf(v[u][3] - mx);
+        sm = wave_sum(sm);
+        const float lse = mx + logf(sm);
+        // the target logit is in a register before any lane overwrites the row
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (counted && lane == 0) acc += lse - tl;
+        if (lane == 0 && lse_out) lse_out[row] = lse;
+        const int tgi = counted ? (int)tg : -1;
+        const float gsr = counted ? gs : 0.f;
+#pragma unroll
+        for (int u = 0; u < NV4; ++u) {
+            const int c = lane + 64 * u;
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (__expf(v[u][k] - lse) - (4 * c + k == tgi ? 1.f : 0.f)) * gsr;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(capdec_i32x4, o), rs, lane * 16, u * 1024, 0);
+        }
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = red[0] + red[1] + red[2] + red[3];
+        if (t != 0.f) atomicAdd(&sums[0], t);
+    }
+}
+
+
 // ---- rows with a counted target first ------------------------------------------------------------------------
 // One workgroup: thread t owns the rows [t*per, (t+1)*per); an exclusive scan over the threads' counts places
 // them, so the order of the counted rows is kept.
@@ -1424,7 +1499,10 @@ int capdec_softmax_nll_grad_rows(float* logits, int64_t ld, const int64_t* targe
                        sums);
     const bool vec = V % 4 == 0 && ld % 4 == 0 && capdec_aligned16(logits);
     const dim3 grid((M + SM_ROWS - 1) / SM_ROWS);
-    if (vec)
+    if (vec && V > 256 * 20 && V <= 256 * 40)
+        hipLaunchKernelGGL(softmax_nll_grad_reg_kernel<40>, grid, dim3(256), 0, (hipStream_t)stream, logits, ld, targets,
+                           M, V, ignore_index, gscale, sums, lse_out, rows_dev);
+    else if (vec)
         hipLaunchKernelGGL(softmax_nll_grad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, logits, ld, targets, M,
                            V, ignore_index, gscale, sums, lse_out, rows_dev);
     else

@@ -118,6 +118,39 @@ def test_vocab_loss_skips_ignored_rows(M, frac_pad):
     assert float(outs[True][1][tgt == 0].abs().max() if (tgt == 0).any() else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("V", [300, 5124, 10000, 10240, 10244])
+def test_softmax_nll_gradient_in_place_every_row_form(V):
+    """logits -> d(mean NLL)/d(logits) in place (train.py:216,254-256): the two-pass kernel (short and very long rows)
+    and the one that keeps a row in registers (5120 < V <= 10240), with ignored targets, against fp64 autograd; then with
+    a device-side row limit: rows up to the next multiple of 32 zeroed, the rest untouched."""
+    from capdec import ops
+    g = torch.Generator().manual_seed(V)
+    M = 70
+    logits = torch.randn(M, V, generator=g) * 3
+    tgt = torch.randint(1, V, (M,), generator=g)
+    tgt[::4] = 0
+    tgt[1] = V - 1
+    ld = logits.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ld, tgt, ignore_index=0)
+    ref.backward()
+    work = logits.clone().cuda()
+    sums, gscale = ops.softmax_nll_grad_(work, tgt.cuda())
+    close(work, ld.grad, atol=1e-9, what="d logits")
+    close(sums[0] / sums[1], ref.detach(), rtol=1e-5, what="loss")
+    assert int(sums[1]) == int((tgt != 0).sum())
+    live = 37
+    rows = torch.tensor([live], dtype=torch.int32, device="cuda")
+    work = logits.clone().cuda()
+    work[64:] = 7.0
+    tl = tgt.clone()
+    ops.softmax_nll_grad_(work, tl.cuda(), rows_dev=rows)
+    ld2 = logits[:live].double().requires_grad_(True)
+    torch.nn.functional.cross_entropy(ld2, tgt[:live], ignore_index=0, reduction="sum").backward()
+    n_all = float((tgt != 0).sum())             # the count runs over every target handed in
+    close(work[:live], ld2.grad / n_all, atol=1e-9, what="d logits, limited rows")
+    assert float(work[live:64].abs().max()) == 0.0 and bool((work[64:] == 7.0).all())
+
+
 def _run_stack(dec, enc, caps, ragged, shortcut=True):
     from capdec import autograd as AG
     from capdec import ops
