@@ -76,7 +76,7 @@ def main():
     dWv = torch.zeros(V, E, device="cuda")
     mfma("gemm_kernel 128x128 (vocab wgrad)", "10000x512x10240", 2.0 * Mt * V * E, lambda: ops.linear_wgrad(logits, xt, out=dWv))
     tg = torch.randint(1, V, (Mt,), generator=g).cuda()
-    hbm("softmax_nll_grad_kernel (in place)", "10240x10000", 2.0 * Mt * V * 4, lambda: ops.softmax_nll_grad_(logits, tg))
+    hbm("softmax_nll_grad_reg_kernel (in place, row in registers)", "10240x10000", 2.0 * Mt * V * 4, lambda: ops.softmax_nll_grad_(logits, tg))
     hbm("ln_train_fwd_kernel (dropout+add+LN)", "10240x512, x,add->y,s", 4.0 * Mt * E * 4,
         lambda: ops.add_layernorm_train(xt, dy, gam, bet, 0.1, 7))
     _, s_, mean, rstd = ops.add_layernorm_train(xt, dy, gam, bet, 0.1, 7)
