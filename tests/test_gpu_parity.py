@@ -284,6 +284,25 @@ def test_f5_greedy_random_weights_cached_and_exact():
             check_greedy(got, sd, enc, int(fx["H"]), 12, want_rows=want)
 
 
+def test_greedy_outputs_packed_on_the_device_and_prebuilt_parameter_struct():
+    """ids, lengths and flags share one device allocation: the host copies (one pinned transfer), the device views
+    (to_cpu=False, what a cross-rank gather takes) and a call through a parameter struct built once must agree."""
+    from capdec.engine import TfModelRef, tf_greedy_ids
+    fx = load_golden("f5_greedy")
+    dec = decoder_from_sd(sub_sd(fx, "a__sd__"), int(fx["H"]))
+    enc = t(fx["a_enc_S2"]).cuda()
+    ids, lens, _ = tf_greedy_ids(dec, enc, 12, R.SOS, R.EOS)
+    assert not ids.is_cuda and ids.dtype == torch.int64 and lens.dtype == torch.int32 and ids.shape == (enc.shape[0], 12)
+    ids_d, lens_d, _ = tf_greedy_ids(dec, enc, 12, R.SOS, R.EOS, to_cpu=False)
+    assert ids_d.is_cuda and torch.equal(ids_d.cpu(), ids) and torch.equal(lens_d.cpu(), lens)
+    ref = TfModelRef(dec)
+    for kw in ({}, {"exact": True}, {"resolve_dirty": False}):
+        ids2, lens2, _ = tf_greedy_ids(ref, enc, 12, R.SOS, R.EOS, **kw)
+        assert torch.equal(ids2, ids) and torch.equal(lens2, lens), kw
+    e0, l0, _ = tf_greedy_ids(ref, enc[:0], 12, R.SOS, R.EOS)
+    assert e0.shape == (0, 12) and l0.shape == (0,)
+
+
 def test_f5_greedy_generated_pad_rows_are_rerun_inside_the_cached_loop():
     """Weights crafted so that most rows emit <PAD> mid-sequence: the cached decoder must reproduce the reference
     (which masks the PAD query row to a uniform softmax over the CURRENT length) without the host fallback when
