@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcapdec.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 GEMM_RELU = 1
 GEMM_TP = 2
 GEMM_TQ = 4
@@ -142,6 +142,7 @@ _SIGNATURES = {
     "capdec_rnn_beam_workspace_bytes": (c_size_t, [POINTER(RnnModel), c_int, c_int, c_int]),
     "capdec_rnn_beam_search": (c_int, [POINTER(RnnModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                        c_size_t, _P, _P, _P, _P, _P]),
+    "capdec_topk_rows": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
 }
 
 _lib = None

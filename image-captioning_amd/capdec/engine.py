@@ -178,6 +178,10 @@ def tf_forward_logits(dec, enc, ids, take_last=False):
     lib = _lib.load()
     if not enc.is_cuda or not ids.is_cuda:
         raise RuntimeError("capdec: inputs must live on the GPU (HIP); there is no CPU path")
+    if enc.dtype != torch.float32:
+        raise RuntimeError(f"capdec: enc must be fp32 (got {enc.dtype}); the kernels read it as float*")
+    if ids.dtype not in (torch.int64, torch.int32):
+        raise RuntimeError(f"capdec: ids must be an integer tensor (got {ids.dtype})")
     enc = enc.contiguous()
     ids = ids.contiguous().to(torch.int64)
     B, S, _ = enc.shape
@@ -230,8 +234,9 @@ BEAM_CHUNK = 8      # decode steps enqueued between two looks at the device-side
 
 
 def _beam_loop(run, B, W, max_length, dev, return_scores):
-    """Drive a beam-search entry point in chunks of steps; stop when every hypothesis is finished (the
-    reference's ``if done.all(): break``).  One 4-byte device-to-host read per chunk."""
+    """Drive a beam-search entry point in chunks of steps; stop once the device reports that all B*W hypotheses
+    produced <EOS> in one step (the reference's ``if done.all(): break``; the device froze the state at that step, so
+    the steps of the chunk that were enqueued past it changed nothing).  One 4-byte device-to-host read per chunk."""
     out_ids = torch.empty((B, max_length), dtype=torch.int64, device=dev)
     out_len = torch.empty((B,), dtype=torch.int32, device=dev)
     scores = torch.empty((B, W), dtype=torch.float32, device=dev)
@@ -271,8 +276,9 @@ def tf_beam_ids(dec, enc, beam_width, max_length, sos, eos, return_scores=False,
 
     By default the KV-cached form runs first; samples in which a hypothesis received a <PAD> token (whose query row
     the reference lets attend uniformly over the current length: no cache can hold that) are then redone with the
-    full-prefix form, so the result is the reference's in every case.  ``exact=True`` uses the full-prefix form for
-    every sample."""
+    full-prefix form, so the captions are the reference's in every case.  ``exact=True`` uses the full-prefix form for
+    every sample.  (The reference leaves its loop when ALL hypotheses of the batch produce <EOS> in one step; a redone
+    subset is a batch of its own in that respect, which can only matter for the scores, never for the captions.)"""
     lib = _lib.load()
     if not enc.is_cuda or enc.dtype != torch.float32:
         raise RuntimeError("capdec: enc must be an fp32 tensor on the GPU (HIP); there is no CPU path")
@@ -285,7 +291,8 @@ def tf_beam_ids(dec, enc, beam_width, max_length, sos, eos, return_scores=False,
     if max_length > ref.max_pos:
         raise RuntimeError(f"capdec: max_length {max_length} exceeds the positional-encoding buffer ({ref.max_pos})")
     if B == 0:
-        return torch.empty((0, max_length), dtype=torch.int64), torch.empty((0,), dtype=torch.int32)
+        empty = (torch.empty((0, max_length), dtype=torch.int64), torch.empty((0,), dtype=torch.int32))
+        return empty + (torch.empty((0, W), dtype=torch.float32),) if return_scores else empty
     dev = enc.device
     with torch.cuda.device(dev):
         if exact:
@@ -325,7 +332,8 @@ def rnn_beam_ids(rnn, x0, beam_width, max_length, sos, eos, return_scores=False)
     if not 1 <= W <= 8:
         raise RuntimeError("capdec: beam_width must be between 1 and 8")
     if B == 0:
-        return torch.empty((0, max_length), dtype=torch.int64), torch.empty((0,), dtype=torch.int32)
+        empty = (torch.empty((0, max_length), dtype=torch.int64), torch.empty((0,), dtype=torch.int32))
+        return empty + (torch.empty((0, W), dtype=torch.float32),) if return_scores else empty
     dev = x0.device
     with torch.cuda.device(dev):
         nbytes = lib.capdec_rnn_beam_workspace_bytes(ctypes.byref(m), B, W, max_length)

@@ -199,57 +199,195 @@ struct BeamState {
     int32_t* tok; float* score; int32_t* done;     // [N][ldtok], [N], [N]
 };
 
-__global__ void beam_init_kernel(BeamState st, int64_t ldtok, int N, int sos) {
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+__global__ void beam_init_kernel(BeamState st, int64_t ldtok, int N, int sos, int32_t* __restrict__ unfinished,
+                                 int max_len) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int n = g; n < N; n += gridDim.x * blockDim.x) {
         st.tok[(int64_t)n * ldtok] = sos;
         st.score[n] = 0.f;
         st.done[n] = 0;
     }
+    for (int t = g; t < max_len; t += gridDim.x * blockDim.x) unfinished[t] = 0;
 }
 
-// One thread per sample: the W*W candidates of its hypotheses, best W kept (best first; ties: lowest candidate
-// index).  Writes the next state (token prefixes copied from the parents), the parent map, and counts the samples
-// that still have an unfinished hypothesis.
+// ---- torch.topk's order among equal values on the CPU, for rows of at most 64 values --------------------------------
+// The reference selects the surviving hypotheses with new_scores.topk(beam_width) (transformer.py:211,
+// cnnrnn_model.py:172), and a hypothesis that has just produced <EOS> contributes W candidates with exactly the same
+// score, so which of several EQUAL candidates survive shapes the rest of the search.  ATen's CPU kernel
+// (topk_impl_loop: k * 64 > n) runs std::nth_element(begin, begin + k - 1, end, greater) and then
+// std::sort(begin, begin + k - 1, greater) over (value, index) pairs; with GNU libstdc++ that is introselect --
+// median of three moved to the front, unguarded Hoare partition, insertion sort below four elements, heap select once
+// the depth limit 2 * floor(log2 n) is used up -- followed by one insertion sort (fewer than 16 elements).  The
+// functions below perform the same element moves, so the result is the same permutation, ties included.
+struct TopkRow {
+    float v[BEAM_MAX_W * BEAM_MAX_W];
+    int i[BEAM_MAX_W * BEAM_MAX_W];
+    __device__ void swap(int a, int b) {
+        const float tv = v[a]; v[a] = v[b]; v[b] = tv;
+        const int ti = i[a]; i[a] = i[b]; i[b] = ti;
+    }
+    __device__ void move(int dst, int src) { v[dst] = v[src]; i[dst] = i[src]; }
+};
+// ATen's comparator for largest = true: NaN first, otherwise strictly greater
+__device__ inline bool topk_gt(float x, float y) { return ((x != x) && !(y != y)) || (x > y); }
+
+__device__ inline int topk_partition_pivot(TopkRow& q, int first, int last) {
+    const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+    int m;
+    if (topk_gt(q.v[a], q.v[b])) m = topk_gt(q.v[b], q.v[c]) ? b : (topk_gt(q.v[a], q.v[c]) ? c : a);
+    else m = topk_gt(q.v[a], q.v[c]) ? a : (topk_gt(q.v[b], q.v[c]) ? c : b);
+    q.swap(first, m);
+    int lo = first + 1, hi = last;
+    const float piv = q.v[first];
+    for (;;) {
+        while (topk_gt(q.v[lo], piv)) ++lo;
+        --hi;
+        while (topk_gt(piv, q.v[hi])) --hi;
+        if (!(lo < hi)) return lo;
+        q.swap(lo, hi);
+        ++lo;
+    }
+}
+
+__device__ inline void topk_insertion_sort(TopkRow& q, int first, int last) {
+    for (int n = first + 1; n < last; ++n) {
+        const float val = q.v[n];
+        const int vi = q.i[n];
+        int j = n;
+        if (topk_gt(val, q.v[first])) {
+            for (; j > first; --j) q.move(j, j - 1);
+        } else {
+            while (topk_gt(val, q.v[j - 1])) { q.move(j, j - 1); --j; }
+        }
+        q.v[j] = val; q.i[j] = vi;
+    }
+}
+
+__device__ inline void topk_adjust_heap(TopkRow& q, int first, int hole, int len, float val, int vi) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (topk_gt(q.v[first + child], q.v[first + child - 1])) --child;
+        q.move(first + hole, first + child);
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        q.move(first + hole, first + child - 1);
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && topk_gt(q.v[first + parent], val)) {
+        q.move(first + hole, first + parent);
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    q.v[first + hole] = val; q.i[first + hole] = vi;
+}
+
+__device__ inline void topk_heap_select(TopkRow& q, int first, int middle, int last) {
+    const int len = middle - first;
+    if (len >= 2)
+        for (int parent = (len - 2) / 2; parent >= 0; --parent)
+            topk_adjust_heap(q, first, parent, len, q.v[first + parent], q.i[first + parent]);
+    for (int n = middle; n < last; ++n)
+        if (topk_gt(q.v[n], q.v[first])) {
+            const float val = q.v[n];
+            const int vi = q.i[n];
+            q.move(n, first);
+            topk_adjust_heap(q, first, 0, len, val, vi);
+        }
+}
+
+// The k best of q.v[0..n) end up in q.v / q.i [0..k), best first, as torch.topk(values, k) returns them on the CPU
+// (1 <= k <= n <= 64, k * 64 > n; q.i must hold 0..n-1 on entry).
+__device__ inline void topk_cpu_order(TopkRow& q, int n, int k) {
+    int first = 0, last = n;
+    const int nth = k - 1;
+    int depth = 2 * (31 - __clz(n));
+    bool selected = false;
+    while (last - first > 3) {
+        if (depth == 0) {
+            topk_heap_select(q, first, nth + 1, last);
+            q.swap(first, nth);
+            selected = true;
+            break;
+        }
+        --depth;
+        const int cut = topk_partition_pivot(q, first, last);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    if (!selected) topk_insertion_sort(q, first, last);
+    topk_insertion_sort(q, 0, k - 1);
+}
+
+__global__ void topk_rows_kernel(const float* __restrict__ x, int rows, int n, int k, float* __restrict__ out_val,
+                                 int32_t* __restrict__ out_idx) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    TopkRow q;
+    for (int c = 0; c < n; ++c) { q.v[c] = x[(int64_t)r * n + c]; q.i[c] = c; }
+    topk_cpu_order(q, n, k);
+    for (int c = 0; c < k; ++c) { out_val[(int64_t)r * k + c] = q.v[c]; out_idx[(int64_t)r * k + c] = q.i[c]; }
+}
+
+// One thread per sample: the W*W candidates of its hypotheses, best W kept in torch.topk's order.  Writes the next
+// state (token prefixes copied from the parents) and the parent map.
+// `done` holds "this hypothesis' last token is <EOS>" and nothing else: the reference's `mask[:, :, 0] = False`
+// (transformer.py:199-201, cnnrnn_model.py:161-163) writes through a stride-0 view and clears its `done` tensor at
+// every step, so a hypothesis is frozen (adds (1 - 1) * log-prob) for the one step after its <EOS>, all W of its
+// proposals stay eligible with that same score, and it accumulates log-probabilities again afterwards; proposals are
+// masked to -inf at the first step only (hypotheses 1.. : all W start identical).
+// unfinished[t] counts the samples that received a token other than <EOS> at step t.  The reference leaves its loop
+// (`if done.all(): break`, transformer.py:231) when that count is 0, i.e. when all B*W hypotheses produced <EOS> in
+// the same step; from then on this kernel passes the state through unchanged (the host may have enqueued further
+// steps without looking), appending <EOS> so that later kernels still read valid token ids.
 __global__ void beam_select_kernel(int step, int B, int W, int eos, BeamState cur, BeamState nxt, int64_t ldtok,
                                    const float* __restrict__ top_lp, const int32_t* __restrict__ top_id,
-                                   int32_t* __restrict__ parent, int32_t* __restrict__ n_unfinished,
+                                   int32_t* __restrict__ parent, int32_t* __restrict__ unfinished,
                                    int32_t* __restrict__ pad_seen = nullptr) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    float cand[BEAM_MAX_W * BEAM_MAX_W];
+    if (step > 0 && unfinished[step - 1] == 0) {           // the reference's loop has ended: keep everything
+        for (int w = 0; w < W; ++w) {
+            const int n = b * W + w;
+            for (int p = 0; p <= step; ++p) nxt.tok[(int64_t)n * ldtok + p] = cur.tok[(int64_t)n * ldtok + p];
+            nxt.tok[(int64_t)n * ldtok + step + 1] = eos;
+            nxt.score[n] = cur.score[n];
+            nxt.done[n] = 1;
+            parent[n] = n;
+        }
+        return;                                            // unfinished[step] stays 0
+    }
+    TopkRow q;
     for (int w = 0; w < W; ++w) {
         const int n = b * W + w;
-        const bool fin = cur.done[n] != 0;
+        const float keep = cur.done[n] != 0 ? 0.f : 1.f;
         for (int k = 0; k < W; ++k) {
-            // a finished hypothesis adds (1 - 1) * log-prob: its score stays, and only its first proposal survives
-            float v = cur.score[n] + (fin ? 0.f : 1.f) * top_lp[(int64_t)n * W + k];
-            if ((fin && k > 0) || (step == 0 && w > 0)) v = -INFINITY;
-            cand[w * W + k] = v;
+            float v = cur.score[n] + keep * top_lp[(int64_t)n * W + k];
+            if (step == 0 && w > 0) v = -INFINITY;
+            q.v[w * W + k] = v;
+            q.i[w * W + k] = w * W + k;
         }
     }
+    topk_cpu_order(q, W * W, W);
     bool every = true;
-    unsigned long long taken = 0ull;
     for (int r = 0; r < W; ++r) {
-        int best = -1;
-        float bvv = 0.f;
-        for (int q = 0; q < W * W; ++q) {
-            if ((taken >> q) & 1ull) continue;
-            if (best < 0 || cand[q] > bvv) { bvv = cand[q]; best = q; }
-        }
-        taken |= 1ull << best;
+        const int best = q.i[r];
         const int pw = best / W, pk = best - pw * W;
         const int src = b * W + pw, dst = b * W + r;
         const int tokn = top_id[(int64_t)src * W + pk];
         for (int p = 0; p <= step; ++p) nxt.tok[(int64_t)dst * ldtok + p] = cur.tok[(int64_t)src * ldtok + p];
         nxt.tok[(int64_t)dst * ldtok + step + 1] = tokn;
-        nxt.score[dst] = bvv;
-        const int fin = (cur.done[src] != 0 || tokn == eos) ? 1 : 0;
+        nxt.score[dst] = q.v[r];
+        const int fin = tokn == eos ? 1 : 0;
         nxt.done[dst] = fin;
         parent[dst] = src;
         if (pad_seen && tokn == 0) pad_seen[b] = 1;      // a <PAD> query row attends uniformly: no cache can hold that
         every = every && fin;
     }
-    if (!every) atomicAdd(n_unfinished, 1);
+    if (!every) atomicAdd(unfinished + step, 1);
 }
 
 // dst[n,:] = src[parent[n],:]
@@ -282,9 +420,11 @@ __global__ __launch_bounds__(256) void beam_cache_gather_kernel(const float* __r
 // Best hypothesis of every sample without <SOS>, cut at its first <EOS> (transformer.py:233-241)
 __global__ void beam_result_kernel(BeamState st, int64_t ldtok, int B, int W, int steps, int max_len, int eos,
                                    int64_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
-                                   float* __restrict__ out_scores) {
+                                   float* __restrict__ out_scores, const int32_t* __restrict__ unfinished,
+                                   int32_t* __restrict__ n_unfinished) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (b == 0) n_unfinished[0] = unfinished[steps - 1];
     const int32_t* row = st.tok + (int64_t)b * W * ldtok;
     int n = 0;
     for (int p = 1; p <= steps; ++p) {
@@ -812,6 +952,7 @@ int capdec_rnn_greedy_decode(const capdec_rnn_model* m, const float* x0, int B, 
 struct BeamBufs {
     float *logits, *top_lp;
     int32_t *top_id, *parent;
+    int32_t* unfinished;      // [max_len]: samples that received a token other than <EOS> at step t
     BeamState st[2];
 };
 
@@ -820,6 +961,7 @@ static void carve_beam_bufs(Carver& c, int N, int W, int V, int max_len, BeamBuf
     d->top_lp = c.take<float>((size_t)N * W);
     d->top_id = c.take<int32_t>((size_t)N * W);
     d->parent = c.take<int32_t>((size_t)N);
+    d->unfinished = c.take<int32_t>((size_t)max_len);
     for (int n = 0; n < 2; ++n) {
         d->st[n].tok = c.take<int32_t>((size_t)N * (max_len + 1));
         d->st[n].score = c.take<float>((size_t)N);
@@ -827,8 +969,8 @@ static void carve_beam_bufs(Carver& c, int N, int W, int V, int max_len, BeamBuf
     }
 }
 
-static int beam_pick(const BeamBufs& d, int t, int B, int W, int V, int eos, int64_t ldtok, int32_t* n_unfinished,
-                     hipStream_t s, int32_t* pad_seen = nullptr) {
+static int beam_pick(const BeamBufs& d, int t, int B, int W, int V, int eos, int64_t ldtok, hipStream_t s,
+                     int32_t* pad_seen = nullptr) {
     const int N = B * W;
     const bool vec = V % 4 == 0 && capdec_aligned16(d.logits);
 #define CAPDEC_TOPK(CAP_)                                                                                               \
@@ -843,9 +985,8 @@ static int beam_pick(const BeamBufs& d, int t, int B, int W, int V, int eos, int
     else CAPDEC_TOPK(BEAM_MAX_W);
 #undef CAPDEC_TOPK
     CAPDEC_LAUNCH_CHECK();
-    if (hipMemsetAsync(n_unfinished, 0, sizeof(int32_t), s) != hipSuccess) return (int)hipGetLastError();
     hipLaunchKernelGGL(beam_select_kernel, dim3((B + 63) / 64), dim3(64), 0, s, t, B, W, eos, d.st[t & 1],
-                       d.st[(t + 1) & 1], ldtok, d.top_lp, d.top_id, d.parent, n_unfinished, pad_seen);
+                       d.st[(t + 1) & 1], ldtok, d.top_lp, d.top_id, d.parent, d.unfinished, pad_seen);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -865,6 +1006,16 @@ static size_t carve_tf_beam(const capdec_tf_model* m, int B, int W, int S, int m
     carve_beam_bufs(c, N, W, m->V, max_len, &d.b);
     if (w) *w = d;
     return head + c.off;
+}
+
+int capdec_topk_rows(const float* x, int rows, int n, int k, float* out_val, int32_t* out_idx, void* stream) {
+    CAPDEC_REQUIRE(x && out_val && out_idx && rows >= 0 && n >= 1 && n <= BEAM_MAX_W * BEAM_MAX_W && k >= 1 && k <= n &&
+                   k <= BEAM_MAX_W && k * 64 > n);
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, rows, n, k, out_val,
+                       out_idx);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
 }
 
 size_t capdec_tf_beam_workspace_bytes(const capdec_tf_model* m, int B, int W, int S, int max_len) {
@@ -887,7 +1038,7 @@ int capdec_tf_beam_search(const capdec_tf_model* m, const float* enc, int B, int
     const int E = m->E, V = m->V, N = B * W;
     const int64_t ldtok = max_len + 1;
     if (t_begin == 0) {
-        hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos);
+        hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos, w.b.unfinished, max_len);
         CAPDEC_LAUNCH_CHECK();
         // every hypothesis of a sample attends to the sample's memory rows (cnnattn_model.py:65-66)
         hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, enc, (const int32_t*)nullptr, W, N,
@@ -902,10 +1053,10 @@ int capdec_tf_beam_search(const capdec_tf_model* m, const float* enc, int B, int
         CAPDEC_TRY(decoder_stack_full(m, w.f.f, w.f.ck, w.f.cv, N, S, T, cur.tok, ldtok, s));
         CAPDEC_TRY(linear(w.f.f.X + (size_t)(T - 1) * E, (int64_t)T * E, N, m->fc2_w, m->fc2_b, V, E, w.b.logits, V,
                           nullptr, 0, 0, s));
-        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, n_unfinished, s));
+        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, s));
     }
     hipLaunchKernelGGL(beam_result_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.b.st[t_end & 1], ldtok, B, W, t_end,
-                       max_len, eos, out_ids, out_len, out_scores);
+                       max_len, eos, out_ids, out_len, out_scores, w.b.unfinished, n_unfinished);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -963,7 +1114,7 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
     const int64_t ldtok = max_len + 1, cstride = (int64_t)max_len * E;
     const bool s1 = S == 1;
     if (t_begin == 0) {
-        hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos);
+        hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos, w.b.unfinished, max_len);
         CAPDEC_LAUNCH_CHECK();
         if (hipMemsetAsync(pad_seen, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return (int)hipGetLastError();
         if (s1) {
@@ -1015,7 +1166,7 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
             CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n3_g, ly.n3_b, 1e-5f, N, E, w.x, nullptr, s));
         }
         CAPDEC_TRY(linear(w.x, E, N, m->fc2_w, m->fc2_b, V, E, w.b.logits, V, nullptr, 0, 0, s));
-        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, n_unfinished, s, pad_seen));
+        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, s, pad_seen));
         if (t + 1 < max_len) {
             const long rows = (long)N * (t + 1);
             hipLaunchKernelGGL(beam_cache_gather_kernel, dim3((unsigned)((rows + 3) / 4), 2 * L), dim3(256), 0, s, cur, nxt,
@@ -1026,7 +1177,7 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
         }
     }
     hipLaunchKernelGGL(beam_result_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.b.st[t_end & 1], ldtok, B, W, t_end,
-                       max_len, eos, out_ids, out_len, out_scores);
+                       max_len, eos, out_ids, out_len, out_scores, w.b.unfinished, n_unfinished);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -1069,7 +1220,7 @@ int capdec_rnn_beam_search(const capdec_rnn_model* m, const float* x0, int B, in
     const int E = m->E, Hd = m->Hd, V = m->V, N = B * W;
     const int64_t ldtok = max_len + 1;
     if (t_begin == 0) {
-        hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos);
+        hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos, w.b.unfinished, max_len);
         CAPDEC_LAUNCH_CHECK();
         // the image is time-step 0 of the LSTM (cnnrnn_model.py:129); every hypothesis starts from that state (:133-134)
         CAPDEC_TRY(capdec_lstm_step(x0, E, nullptr, 0, nullptr, m->w_ih, m->w_hh, m->b_ih, m->b_hh, B, E, Hd, w.h[1], Hd,
@@ -1086,14 +1237,14 @@ int capdec_rnn_beam_search(const capdec_rnn_model* m, const float* x0, int B, in
         CAPDEC_TRY(capdec_lstm_step(w.x, E, w.h[0], Hd, w.c[0], m->w_ih, m->w_hh, m->b_ih, m->b_hh, N, E, Hd, w.h[1], Hd,
                                     w.c[1], nullptr, stream));
         CAPDEC_TRY(linear(w.h[1], Hd, N, m->fc2_w, m->fc2_b, V, Hd, w.b.logits, V, nullptr, 0, 0, s));
-        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, n_unfinished, s));
+        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, s));
         // the state of every surviving hypothesis follows its parent (cnnrnn_model.py:186-188)
         hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w.h[1], w.b.parent, 1, N, Hd, w.h[0]);
         hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w.c[1], w.b.parent, 1, N, Hd, w.c[0]);
         CAPDEC_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(beam_result_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.b.st[t_end & 1], ldtok, B, W, t_end,
-                       max_len, eos, out_ids, out_len, out_scores);
+                       max_len, eos, out_ids, out_len, out_scores, w.b.unfinished, n_unfinished);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

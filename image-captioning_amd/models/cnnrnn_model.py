@@ -65,12 +65,13 @@ class CNNtoRNN(nn.Module):
         itos = vocabulary.itos
         return [" ".join(itos[i] for i in row) for row in engine.ids_to_lists(ids, lengths)]
 
-    def caption_ids_beam(self, images, sos=1, eos=2, beam_width=3, mode="precomputed", max_length=50):
-        """Beam search returning token ids: (ids int64 [B,max_length] padded with -1, lengths [B])."""
+    def caption_ids_beam(self, images, sos=1, eos=2, beam_width=3, mode="precomputed", max_length=50,
+                         return_scores=False):
+        """Beam search returning token ids: (ids int64 [B,max_length] padded with -1, lengths [B][, scores [B,W]])."""
         self.eval()
         with torch.no_grad():
             x0 = self.decoderRNN.image_input(self._features(images, mode))
-            return engine.rnn_beam_ids(self.decoderRNN, x0, beam_width, max_length, sos, eos)
+            return engine.rnn_beam_ids(self.decoderRNN, x0, beam_width, max_length, sos, eos, return_scores)
 
     def caption_images_beam_search(self, images, vocabulary, beam_width=3, mode="precomputed", max_length=50):
         """Reference :112-209: list of B space-joined captions (best hypothesis, cut at its first <EOS>)."""

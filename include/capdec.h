@@ -29,7 +29,7 @@ extern "C" {
 #define CAPDEC_ENOMEM (-12)   /* caller-provided workspace too small        */
 #define CAPDEC_EALIGN (-14)   /* pointer not 16-byte aligned where required */
 
-#define CAPDEC_ABI_VERSION 1
+#define CAPDEC_ABI_VERSION 2
 int capdec_abi_version(void);
 /* static string for a return code of this library (never NULL) */
 const char* capdec_strerror(int code);
@@ -388,15 +388,20 @@ int capdec_rnn_greedy_decode(const capdec_rnn_model* m, const float* x0, int B, 
 /* ------------------------------------------------------------------------------------------
  * Beam search.  Replaces DecoderTransformer.beam_search_inference (transformer.py:177-244) and the loop of
  * CNNtoRNN.caption_images_beam_search (cnnrnn_model.py:131-197).  B samples, W hypotheses each (W <= 8); all B*W
- * hypotheses are extended every step: per hypothesis the W most probable next tokens (log-softmax), finished
- * hypotheses keep their score and one proposal, the first step expands hypothesis 0 only, the best W of the W*W
- * candidates survive (best first).  The Transformer form recomputes the full prefix each step, as the reference
- * does, so generated <PAD> tokens behave exactly as there.
+ * hypotheses are extended every step: per hypothesis the W most probable next tokens (log-softmax); the first step
+ * expands hypothesis 0 only; the best W of the W*W candidates survive, in the order torch.topk returns them on the CPU
+ * (equal scores included, see capdec_topk_rows).  <EOS> follows the reference's code, not its comments: its
+ * `mask[:, :, 0] = False` (transformer.py:199-201, cnnrnn_model.py:161-163) writes through a stride-0 view and clears
+ * the `done` tensor at every step, so a hypothesis is frozen only for the one step after its <EOS> (its W proposals
+ * all carry its unchanged score and all stay eligible), accumulates log-probabilities again afterwards, and the loop
+ * ends early only when all B*W hypotheses produce <EOS> in the same step.  The Transformer form recomputes the full
+ * prefix each step, as the reference does, so generated <PAD> tokens behave exactly as there.
  * One call runs steps [t_begin, t_end) (t_begin == 0 initialises the state held in the workspace) and then writes
  * the current best hypothesis of every sample (without <SOS>, cut at its first <EOS>) to out_ids [B,max_len] (padded
  * with -1) / out_len [B], the W scores to out_scores [B,W] (nullable), and to n_unfinished[0] (device) the number of
- * samples that still have an unfinished hypothesis: the caller may stop issuing steps once it reads 0 there (the
- * reference's `if done.all(): break`); further steps would not change the result.
+ * samples that received a token other than <EOS> at step t_end - 1.  0 there is the reference's
+ * `if done.all(): break`: the state is frozen on the device from that step on, so steps already enqueued beyond it do
+ * not change the result and the caller may stop issuing more.
  * ------------------------------------------------------------------------------------------ */
 size_t capdec_tf_beam_workspace_bytes(const capdec_tf_model* m, int B, int W, int S, int max_len);
 int capdec_tf_beam_search(const capdec_tf_model* m, const float* enc /*[B,S,E]*/, int B, int W, int S, int max_len,
@@ -416,6 +421,13 @@ size_t capdec_rnn_beam_workspace_bytes(const capdec_rnn_model* m, int B, int W, 
 int capdec_rnn_beam_search(const capdec_rnn_model* m, const float* x0, int B, int W, int max_len, int sos, int eos,
                            int t_begin, int t_end, void* workspace, size_t workspace_bytes, int64_t* out_ids,
                            int32_t* out_len, float* out_scores, int32_t* n_unfinished, void* stream);
+
+/* torch.topk(x, k, dim=-1) (largest, sorted) over `rows` short rows x [rows, n], n <= 64, k <= 8, k * 64 > n, with the
+ * order among EQUAL values that ATen's CPU kernel produces (std::nth_element + std::sort over (value, index) pairs,
+ * GNU libstdc++): the selection step of the reference's beam search (transformer.py:211, cnnrnn_model.py:172), where
+ * exact ties are routine (a hypothesis that has just produced <EOS> proposes W candidates with one score).
+ * out_val, out_idx [rows, k].  The beam-search entry points above use the same device routine internally. */
+int capdec_topk_rows(const float* x, int rows, int n, int k, float* out_val, int32_t* out_idx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Soft-attention LSTM decoder (additive attention over the memory rows feeding an LSTM cell).

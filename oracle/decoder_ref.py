@@ -290,22 +290,32 @@ def cnnrnn_greedy_ids(sd: SD, feats: torch.Tensor, max_length: int, sos: int = S
 # --------------------------------------------------------------------------
 # beam search (transformer.py:177-244, cnnrnn_model.py:112-209): identical selection logic in both
 # --------------------------------------------------------------------------
-def beam_select(step: int, scores: torch.Tensor, done: torch.Tensor, logits: torch.Tensor, W: int):
-    """One selection step.  scores, done [B,W]; logits [B,W,V] of every live hypothesis.
+def beam_select(step: int, scores: torch.Tensor, fin: torch.Tensor, logits: torch.Tensor, W: int):
+    """One selection step.  scores [B,W]; fin [B,W]: the hypothesis' LAST token is <EOS>; logits [B,W,V].
 
-    Each hypothesis proposes its W most probable next tokens (log-softmax, ``topk``).  A finished hypothesis
-    keeps its score (its proposals add 0) and only its first proposal stays eligible; at the first step only
-    hypothesis 0 is eligible (all W start identical).  The best W of the W*W candidates survive, best first.
+    Each hypothesis proposes its W most probable next tokens (log-softmax, ``topk``).  What the reference's code does
+    with a hypothesis that has produced <EOS> is narrower than its comments say.  ``mask = done.unsqueeze(-1)
+    .expand(-1, -1, beam_width)`` is a stride-0 VIEW of ``done``, so ``mask[:, :, 0] = False`` (transformer.py:199-201,
+    cnnrnn_model.py:161-163) clears ``done`` itself, for every hypothesis, at every step.  Consequences, all reproduced
+    here:
+      * ``done`` only ever holds "the token chosen at the previous step was <EOS>" (transformer.py:226-227 ORs the new
+        <EOS> flags into an all-False tensor);
+      * in the one step after its <EOS> a hypothesis adds ``(1 - 1) * log_prob`` (transformer.py:194-196, evaluated before
+        the write): its W proposals all carry its unchanged score and ALL stay eligible -- the mask is all False by then,
+        so nothing is set to -inf except at the first step (transformer.py:202-205: only hypothesis 0 expands);
+      * from the next step on it accumulates log-probabilities again;
+      * ``if done.all(): break`` (transformer.py:231) fires only when every hypothesis of every sample produced <EOS>
+        in the same step.
+    The best W of the W*W candidates survive, ordered as ``torch.topk`` orders them (among equal scores: the CPU
+    kernel's order, restated in oracle/topk_order.py).
     Returns (new scores [B,W], parent hypothesis [B,W], new token [B,W]).
     (transformer.py:189-219 == cnnrnn_model.py:151-180)"""
     B = scores.shape[0]
     lp, tok = torch.log_softmax(logits, dim=-1).topk(W, dim=2)                       # [B,W,W]
-    cand = scores.unsqueeze(-1) + (1.0 - done.unsqueeze(-1).float()) * lp
-    dead = done.unsqueeze(-1).expand(-1, -1, W).clone()
-    dead[:, :, 0] = False
+    cand = scores.unsqueeze(-1) + (1.0 - fin.unsqueeze(-1).float()) * lp
     if step == 0:
-        dead[:, 1:, :] = True
-    cand = cand.masked_fill(dead, float("-inf")).reshape(B, W * W)
+        cand[:, 1:, :] = float("-inf")
+    cand = cand.reshape(B, W * W)
     new_scores, flat = cand.topk(W, dim=-1)
     parent = flat // W
     new_tok = tok.reshape(B, W * W).gather(1, flat)
@@ -324,8 +334,9 @@ def beam_search_ids(sd: SD, enc: torch.Tensor, H: int, W: int, max_length: int, 
                     return_state: bool = False):
     """``DecoderTransformer.beam_search_inference`` up to detokenisation (transformer.py:177-244).
     enc [B,S,E] (one memory per sample; the reference's callers repeat it W times, e.g. cnnattn_model.py:65-66).
-    Full-prefix recompute of all B*W hypotheses every step; finished hypotheses keep being extended with their
-    most probable token while their score stays frozen."""
+    Full-prefix recompute of all B*W hypotheses every step; every hypothesis keeps being extended whether or not it
+    contains <EOS> (see ``beam_select`` for what <EOS> does to the scores); the loop stops early only when all B*W
+    hypotheses produce <EOS> in the same step."""
     B = enc.shape[0]
     enc_w = enc.unsqueeze(1).expand(-1, W, -1, -1).reshape(B * W, enc.shape[1], enc.shape[2])
     seqs = torch.full((B, W, 1), sos, dtype=torch.long)
@@ -335,7 +346,7 @@ def beam_search_ids(sd: SD, enc: torch.Tensor, H: int, W: int, max_length: int, 
         logits = decoder_forward(sd, enc_w, seqs.reshape(B * W, -1), H, take_last=True).reshape(B, W, -1)
         scores, parent, new_tok = beam_select(step, scores, done, logits, W)
         seqs = torch.cat([seqs.gather(1, parent.unsqueeze(-1).expand(-1, -1, seqs.shape[2])), new_tok.unsqueeze(-1)], dim=2)
-        done = done.gather(1, parent) | (new_tok == eos)
+        done = new_tok == eos          # transformer.py:226-227 on a `done` that :201 has cleared
         if bool(done.all()):
             break
     res = _beam_result(seqs, eos)
@@ -362,7 +373,7 @@ def cnnrnn_beam_search_ids(sd: SD, feats: torch.Tensor, W: int, max_length: int,
         seqs = torch.cat([seqs.gather(1, parent.unsqueeze(-1).expand(-1, -1, seqs.shape[2])), new_tok.unsqueeze(-1)], dim=2)
         idx = (torch.arange(B).unsqueeze(1) * W + parent).reshape(B * W)
         h, c = h[idx], c[idx]
-        done = done.gather(1, parent) | (new_tok == eos)
+        done = new_tok == eos          # cnnrnn_model.py:191-192 on a `done` that :163 has cleared
         if bool(done.all()):
             break
     res = _beam_result(seqs, eos)

@@ -40,7 +40,8 @@ def test_f11_transformer_beam_search(case):
     for exact in (False, True):          # KV-cached (with the <PAD> samples redone) and full-prefix everywhere
         ids, lengths, scores = dec.beam_ids(enc.cuda(), R.SOS, R.EOS, W, ml, return_scores=True, exact=exact)
         assert _rows(ids, lengths) == want, exact
-        # the hypothesis scores (sums of log-probabilities, frozen once finished) against the oracle's
+        # the hypothesis scores (sums of log-probabilities) against the oracle's, which
+        # tests/test_oracle_golden.py::test_f12_beam_search_after_eos pins to the reference's own
         close(scores, want_scores, rtol=1e-4, atol=1e-5, what="scores")
 
 
@@ -123,3 +124,77 @@ def test_cached_beam_equals_full_prefix_beam_at_batch_256():
         assert sum(x != y for x, y in zip(ra, rb)) <= 2
         same = [i for i, (x, y) in enumerate(zip(ra, rb)) if x == y]
         close(a[2][same], b[2][same], rtol=1e-4, atol=1e-4, what="scores")
+
+
+def _peaked_sd(fx, prefix, scale, eos_bias):
+    sd = sub_sd(fx, prefix)
+    sd["fc2.weight"] = sd["fc2.weight"] * float(scale)
+    b = sd["fc2.bias"].clone()
+    b[2] += float(eos_bias)
+    sd["fc2.bias"] = b
+    return sd
+
+
+def test_topk_rows_orders_equal_values_as_torch_topk_on_the_cpu():
+    """The selection routine of the beam search, alone: rows full of ties for every width up to 8."""
+    import ctypes
+    from capdec import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for W in range(1, 9):
+        n = W * W
+        rows = 512
+        levels = torch.tensor([-0.5, -1.0, -2.25, -3.0, float("-inf")])
+        x = levels[torch.randint(0, 5, (rows, n), generator=g)]
+        x[: rows // 4] = torch.randn(rows // 4, n, generator=g)
+        # beam-like rows: groups of W equal values next to groups of falling values
+        grp = -5 * torch.rand(rows // 4, W, 1, generator=g)
+        fall = grp - torch.cumsum(torch.rand(rows // 4, W, W, generator=g), dim=2)
+        frozen = (torch.rand(rows // 4, W, 1, generator=g) < 0.5)
+        x[rows // 4: rows // 2] = torch.where(frozen, grp.expand(-1, -1, W), fall).reshape(rows // 4, n)
+        want_v, want_i = x.topk(W, dim=-1)
+        xd = x.cuda().contiguous()
+        ov = torch.empty((rows, W), dtype=torch.float32, device="cuda")
+        oi = torch.empty((rows, W), dtype=torch.int32, device="cuda")
+        _lib.check(lib.capdec_topk_rows(xd.data_ptr(), rows, n, W, ov.data_ptr(), oi.data_ptr(),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "capdec_topk_rows")
+        assert torch.equal(oi.cpu().long(), want_i), W
+        assert torch.equal(ov.cpu(), want_v), W
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_f12_transformer_beam_search_after_eos(exact):
+    """Peaked output distributions (hypotheses end at every length): captions and final scores of the reference's own
+    run, widths 2, 3, 5, 8; and the one-sample search the reference leaves early (its state must stay frozen through
+    the steps that were enqueued past that point)."""
+    fx = load_golden("f12_beam_peaked")
+    H = int(fx["H"])
+    enc = t(fx["t_enc"])
+    for n, (scale, eos_bias, W) in enumerate(fx["tf_cases"]):
+        dec = decoder_from_sd(_peaked_sd(fx, "t__sd__", scale, eos_bias), H)
+        ml = fx[f"t{n}_ids"].shape[1]
+        ids, lengths, scores = dec.beam_ids(enc.cuda(), R.SOS, R.EOS, int(W), ml, return_scores=True, exact=exact)
+        assert _rows(ids, lengths) == unpad(fx[f"t{n}_ids"]), (n, exact)
+        close(scores, t(fx[f"t{n}_scores"]), rtol=1e-4, atol=1e-5, what=f"scores of case {n}")
+    dec = decoder_from_sd(_peaked_sd(fx, "t__sd__", 6.0, 3.0), H)
+    b, W = int(fx["te_row"]), int(fx["te_W"])
+    ml = fx["te_ids"].shape[1]
+    ids, lengths, scores = dec.beam_ids(enc[b:b + 1].cuda(), R.SOS, R.EOS, W, ml, return_scores=True, exact=exact)
+    assert _rows(ids, lengths) == unpad(fx["te_ids"])
+    close(scores, t(fx["te_scores"]), rtol=1e-4, atol=1e-5, what="scores of the search that ends early")
+
+
+def test_f12_cnn_rnn_beam_search_after_eos():
+    from models.cnnrnn_model import CNNtoRNN
+    fx = load_golden("f12_beam_peaked")
+    feats = t(fx["r_feats"]).cuda()
+    for n, (scale, eos_bias, W) in enumerate(fx["rnn_cases"]):
+        sd = _peaked_sd(fx, "r__sd__", scale, eos_bias)
+        E, Hd, V = sd["fc1.weight"].shape[0], sd["lstm.weight_hh_l0"].shape[1], sd["embed.weight"].shape[0]
+        m = CNNtoRNN(E, Hd, V)
+        m.decoderRNN.load_state_dict(sd)
+        m = m.cuda().eval()
+        ml = fx[f"r{n}_ids"].shape[1]
+        ids, lengths, scores = m.caption_ids_beam(feats, beam_width=int(W), max_length=ml, return_scores=True)
+        assert _rows(ids, lengths) == unpad(fx[f"r{n}_ids"]), n
+        close(scores, t(fx[f"r{n}_scores"]), rtol=1e-4, atol=1e-5, what=f"scores of case {n}")

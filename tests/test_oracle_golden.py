@@ -204,3 +204,71 @@ def test_f11_beam_search_transformer_and_rnn():
     sdr2 = dict(sdr)
     sdr2["fc2.bias"] = t(fx["r__fc2.bias_biased"])
     assert R.cnnrnn_beam_search_ids(sdr2, t(fx["r_feats"]), 3, 15) == unpad(fx["r_ids"])
+
+
+def _peaked_sd(fx, prefix, scale, eos_bias):
+    sd = sub_sd(fx, prefix)
+    sd["fc2.weight"] = sd["fc2.weight"] * float(scale)
+    b = sd["fc2.bias"].clone()
+    b[2] += float(eos_bias)
+    sd["fc2.bias"] = b
+    return sd
+
+
+def test_f12_beam_search_after_eos():
+    """Peaked output distributions: hypotheses end at every length.  Captions, final hypothesis scores and the number
+    of steps the loop ran, all taken from the reference's own run (the scores through a tap on its second topk), for
+    the Transformer and the LSTM decoder at widths 2, 3, 5 and 8, plus a one-sample search that the reference leaves
+    early because all hypotheses produce <EOS> in the same step."""
+    fx = load_golden("f12_beam_peaked")
+    H = int(fx["H"])
+    enc = t(fx["t_enc"])
+    for n, (scale, eos_bias, W) in enumerate(fx["tf_cases"]):
+        sd = _peaked_sd(fx, "t__sd__", scale, eos_bias)
+        ml = fx[f"t{n}_ids"].shape[1]
+        got, seqs, scores = R.beam_search_ids(sd, enc, H, int(W), ml, return_state=True)
+        assert got == unpad(fx[f"t{n}_ids"]), n
+        assert seqs.shape[2] - 1 == int(fx[f"t{n}_steps"])
+        assert torch.allclose(scores, t(fx[f"t{n}_scores"]), rtol=1e-5, atol=1e-5), n
+    sd = _peaked_sd(fx, "t__sd__", 6.0, 3.0)
+    b, W = int(fx["te_row"]), int(fx["te_W"])
+    got, seqs, scores = R.beam_search_ids(sd, enc[b:b + 1], H, W, fx["te_ids"].shape[1], return_state=True)
+    assert got == unpad(fx["te_ids"])
+    assert seqs.shape[2] - 1 == int(fx["te_steps"]) < fx["te_ids"].shape[1]
+    assert torch.allclose(scores, t(fx["te_scores"]), rtol=1e-5, atol=1e-5)
+    feats = t(fx["r_feats"])
+    for n, (scale, eos_bias, W) in enumerate(fx["rnn_cases"]):
+        sd = _peaked_sd(fx, "r__sd__", scale, eos_bias)
+        ml = fx[f"r{n}_ids"].shape[1]
+        got, seqs, scores = R.cnnrnn_beam_search_ids(sd, feats, int(W), ml, return_state=True)
+        assert got == unpad(fx[f"r{n}_ids"]), n
+        assert seqs.shape[2] - 1 == int(fx[f"r{n}_steps"])
+        assert torch.allclose(scores, t(fx[f"r{n}_scores"]), rtol=1e-5, atol=1e-5), n
+
+
+def test_topk_order_matches_torch():
+    """The restated order of torch.topk among equal values (oracle/topk_order.py) against torch.topk itself on rows
+    full of ties: the W*W candidate rows of a beam-search step for every width up to 8."""
+    import random
+    from oracle.topk_order import topk_cpu_order
+    rnd = random.Random(0)
+    for W in range(1, 9):
+        n = W * W
+        for trial in range(400):
+            mode = trial % 4
+            if mode == 0:
+                vals = [rnd.choice([-1.0, -2.0, -3.5, float("-inf")]) for _ in range(n)]
+            elif mode == 1:
+                vals = [rnd.gauss(0, 1) for _ in range(n)]
+            elif mode == 2:      # some hypotheses frozen (W equal proposals), the others with falling log-probs
+                vals = []
+                for _ in range(W):
+                    s = -rnd.random() * 5
+                    vals += [s] * W if rnd.random() < 0.5 else sorted((s - rnd.random() * 3 for _ in range(W)), reverse=True)
+            else:                # first step: only hypothesis 0 is eligible
+                vals = [rnd.gauss(0, 1) for _ in range(W)] + [float("-inf")] * (n - W)
+            x = torch.tensor(vals, dtype=torch.float32)
+            want_v, want_i = x.topk(W)
+            got_v, got_i = topk_cpu_order(x.tolist(), W)
+            assert got_i == want_i.tolist(), (W, vals)
+            assert got_v == want_v.tolist()
