@@ -16,6 +16,8 @@ GEMM_TP = 2
 GEMM_TQ = 4
 GEMM_ATOMIC = 8
 DECODE_NO_S1_SHORTCUT = 1
+VOCAB_STATIC_MAX_ELEMS = 1 << 20
+E2BIG = -7
 
 
 class GemmGroup(Structure):
@@ -143,6 +145,7 @@ _SIGNATURES = {
     "capdec_rnn_beam_search": (c_int, [POINTER(RnnModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                        c_size_t, _P, _P, _P, _P, _P]),
     "capdec_topk_rows": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "capdec_vocab_argmax_static": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
 }
 
 _lib = None

@@ -13,6 +13,7 @@
 // registers (mainloop: rows padded to BK+4 floats, zero fill for ragged K).  Either way the ds_read_b128
 // fragment reads (32 rows x 16 B per half-wave) are bank-conflict free and the sums run in the same order.
 #include "common.h"
+#include <mutex>
 #include <limits.h>
 #include <math.h>
 
@@ -989,6 +990,54 @@ int capdec_argmax_finalize(const float* part_val, const int32_t* part_idx, int M
     if (M == 0) return 0;
     hipLaunchKernelGGL(argmax_finalize_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, part_val,
                        part_idx, M, ntiles, out_idx, out_val);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- allocation-free vocabulary arg-max -------------------------------------------------------------------------
+// The per-tile winners live in a device array that is part of the library's image instead of a caller workspace.
+// Every GPU the library runs on holds its own copy of the array at its own address for the life of the process; in
+// host code the array's NAME is only a handle for hipGetSymbolAddress, never a device address.
+constexpr size_t VOCAB_STATIC_ELEMS = (size_t)CAPDEC_VOCAB_STATIC_MAX_ELEMS;
+static __device__ __align__(256) unsigned char scratch[VOCAB_STATIC_ELEMS * (sizeof(float) + sizeof(int32_t))];
+
+constexpr int STATIC_MAX_DEVICES = 64;
+static std::mutex g_scratch_mutex;
+static unsigned char* g_scratch_ptr[STATIC_MAX_DEVICES];     // per device; nullptr until resolved on that device
+
+// Device address of `scratch` on the current device (resolved once per device, with that device current).
+static int scratch_address(unsigned char** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= STATIC_MAX_DEVICES) return CAPDEC_EINVAL;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!ptr) return CAPDEC_EINVAL;
+        g_scratch_ptr[dev] = static_cast<unsigned char*>(ptr);
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+int capdec_vocab_argmax_static(const float* x, int64_t ldx, const float* W, const float* bias, int M, int V, int K,
+                               int32_t* out_idx, float* out_val, void* stream) {
+    CAPDEC_REQUIRE(x && W && bias && out_idx && M >= 0 && V >= 1 && K >= 1 && ldx >= K);
+    const size_t elems = capdec_vocab_partial_elems(M, V);
+    if (elems > VOCAB_STATIC_ELEMS) return CAPDEC_E2BIG;
+    if (M == 0) return 0;
+    unsigned char* base = nullptr;
+    CAPDEC_TRY(scratch_address(&base));
+    // values first, ids behind them; every (row < M, tile) slot that the merge reads is written by the projection
+    // kernel of the same call, so nothing has to be cleared between calls
+    float* part_val = reinterpret_cast<float*>(base);
+    int32_t* part_idx = reinterpret_cast<int32_t*>(base + VOCAB_STATIC_ELEMS * sizeof(float));
+    CAPDEC_TRY(vocab_reduce_launch(0, x, ldx, W, bias, M, V, K, part_val, part_idx, (hipStream_t)stream));
+    hipLaunchKernelGGL(argmax_finalize_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, part_val, part_idx, M,
+                       capdec_vocab_tiles(V), out_idx, out_val);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

@@ -645,6 +645,7 @@ const char* capdec_strerror(int code) {
         case CAPDEC_EINVAL: return "capdec: invalid argument (shape, null pointer or unsupported size)";
         case CAPDEC_ENOMEM: return "capdec: workspace too small";
         case CAPDEC_EALIGN: return "capdec: pointer or stride not 16-byte aligned";
+        case CAPDEC_E2BIG: return "capdec: problem exceeds the fixed capacity of this allocation-free entry point";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "capdec: unknown error";
     }
 }

@@ -28,6 +28,7 @@ extern "C" {
 #define CAPDEC_EINVAL (-22)   /* bad shape / null pointer / unsupported size */
 #define CAPDEC_ENOMEM (-12)   /* caller-provided workspace too small        */
 #define CAPDEC_EALIGN (-14)   /* pointer not 16-byte aligned where required */
+#define CAPDEC_E2BIG (-7)     /* problem larger than the fixed capacity of an allocation-free entry point */
 
 #define CAPDEC_ABI_VERSION 2
 int capdec_abi_version(void);
@@ -108,6 +109,21 @@ int capdec_vocab_argmax_partial(const float* x, int64_t ldx, const float* W, con
                                 int K, float* part_val, int32_t* part_idx, void* stream);
 int capdec_argmax_finalize(const float* part_val, const int32_t* part_idx, int M, int ntiles,
                            int32_t* out_idx, float* out_val /*nullable*/, void* stream);
+
+/* Allocation-free form of capdec_vocab_argmax_partial + capdec_argmax_finalize: out_idx[M] (and out_val[M], nullable)
+ * = arg-max / max over the vocabulary of x W^T + bias, ties to the lowest index, bit-identical to the two-call form.
+ * It has no counterpart in the reference.  It exists for callers that cannot allocate device memory or hand over a
+ * workspace: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The per-tile winners
+ * go to a fixed device array inside the library (CAPDEC_VOCAB_STATIC_MAX_ELEMS values + ids = 8 MiB, held by every GPU
+ * the library runs on until the process ends); the call performs no hipMalloc / hipFree and calls no allocating
+ * routine.  Limit: capdec_vocab_partial_elems(M, V) <= CAPDEC_VOCAB_STATIC_MAX_ELEMS (e.g. M = 4096 rows at
+ * V = 16384, or M = 6656 at V = 10000), otherwise CAPDEC_E2BIG and nothing is launched.  All calls on one GPU share
+ * that GPU's array: calls that overlap in time on one GPU (different streams or threads) race and must be serialised
+ * by the caller; back-to-back calls on one stream are safe, and nothing needs clearing between calls.  The first call
+ * on a device resolves the array's address there (hipGetSymbolAddress): make it outside graph capture. */
+#define CAPDEC_VOCAB_STATIC_MAX_ELEMS (1 << 20)
+int capdec_vocab_argmax_static(const float* x, int64_t ldx, const float* W, const float* bias, int M, int V, int K,
+                               int32_t* out_idx, float* out_val, void* stream);
 
 /* Vocabulary projection fused with log-sum-exp + target pick (CrossEntropyLoss(ignore_index)):
  *   replaces fc2 + criterion, transformer.py:137 + train.py:216,254-256.
