@@ -82,7 +82,7 @@ _SIGNATURES = {
     "capdec_gemm_force_staging": (c_int, [c_int]),
     "capdec_lstm_force_staging": (c_int, [c_int]),
     "capdec_gemm_ex": (c_int, [POINTER(GemmGroup), c_int, c_int, c_int, POINTER(GemmExtra), _P]),
-    "capdec_dropout": (c_int, [_P, c_int64, c_float, c_uint64, _P, _P]),
+    "capdec_dropout": (c_int, [_P, c_int64, c_float, c_uint64, _P, _P, _P]),
     "capdec_add_layernorm_train": (c_int, [_P, c_int, _P, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
     "capdec_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P, _P]),
     "capdec_colsum": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
@@ -99,8 +99,9 @@ _SIGNATURES = {
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
     "capdec_loss_finish": (c_int, [_P, _P, _P, _P]),
     "capdec_add_layernorm_train_rows": (c_int, [_P, c_int, _P, _P, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P,
-                                                _P, _P, _P, _P]),
-    "capdec_layernorm_bwd_rows": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P, _P, _P]),
+                                                _P, _P, _P, _P, _P]),
+    "capdec_layernorm_bwd_rows": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P, _P, _P,
+                                          _P]),
     "capdec_group_sum_segments": (c_int, [_P, c_int, _P, c_int, _P, _P]),
     "capdec_embed_bwd_rows": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "capdec_compact_prefix": (c_int, [_P, _P, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -144,6 +145,8 @@ _SIGNATURES = {
     "capdec_rnn_beam_workspace_bytes": (c_size_t, [POINTER(RnnModel), c_int, c_int, c_int]),
     "capdec_rnn_beam_search": (c_int, [POINTER(RnnModel), _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                        c_size_t, _P, _P, _P, _P, _P]),
+    "capdec_train_state_advance": (c_int, [_P, c_float, c_float, _P]),
+    "capdec_adam_step_dev": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, _P, c_float, _P]),
     "capdec_topk_rows": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "capdec_vocab_argmax_static": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
 }

@@ -99,18 +99,20 @@ def ragged_supported(dec, S, T, B=1):
             ((T + 64) * (dk + 16) + 128) * 4 <= 144 * 1024)
 
 
-def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
+def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, seed_dev=None):
     """Teacher-forced decoder stack (reference transformer.py:125-132) keeping what the backward needs.
     enc [B,S,E] fp32, ids [B,T] int64.  Returns (x [B*T,E] post-LN output of the last layer, tape).
 
     ragged (ops.RaggedRows of the same ids and their targets; needs ``ragged_supported``): the stack runs on the live
     rows only (the memories, and with them the K/V projections of the cross-attention, stay dense).  Every [B*T,E] tensor is then indexed by slot, the first ``ragged.rows[0]`` rows exist, and the caller
-    takes the loss against ``ragged.targets_c`` with that row limit.  The dropout masks are drawn per slot."""
+    takes the loss against ``ragged.targets_c`` with that row limit.  The dropout masks are drawn per slot.
+    seed_dev (int64 device tensor, optional): its first element is added to ``seed`` by every kernel that draws a mask
+    (a step captured in a HIP graph keeps ``seed`` for ever; the device value changes from replay to replay)."""
     B, S, E = enc.shape
     T = ids.shape[1]
     M, H = B * T, dec.num_heads
     t = Tape()
-    t.B, t.S, t.T, t.E, t.H, t.p, t.seed = B, S, T, E, H, p, seed
+    t.B, t.S, t.T, t.E, t.H, t.p, t.seed, t.seed_dev = B, S, T, E, H, p, seed, seed_dev
     t.shortcut = S == 1 and single_row_shortcut
     t.ids = ids.contiguous()
     t.ids32 = t.ids.to(torch.int32)
@@ -128,7 +130,7 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
         x = x.index_select(0, ragged.order)
         t.ids_c = t.ids.view(-1).index_select(0, ragged.order)
     if p > 0:
-        x = ops.dropout(x, p, seed)
+        x = ops.dropout(x, p, seed, seed_dev=seed_dev)
     t.layers = []
     pre_cc = None
     if t.shortcut and _side() is not None:
@@ -157,7 +159,8 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
         else:
             c.ao, c.lse = ops.attention(qkv[0], qkv[1], qkv[2], B, H, T, T, causal=True, ids32=t.ids32, want_lse=True)
         a = ops.linear(c.ao, sa.W_o.weight, sa.W_o.bias, rows_dev=rows)
-        c.x1, c.s1, c.m1, c.r1 = ops.add_layernorm_train(a, x, ly.norm1.weight, ly.norm1.bias, p, sd, rows_dev=rows)
+        c.x1, c.s1, c.m1, c.r1 = ops.add_layernorm_train(a, x, ly.norm1.weight, ly.norm1.bias, p, sd, rows_dev=rows,
+                                                         seed_dev=seed_dev)
         if S == 1 and single_row_shortcut:
             # one memory row: the softmax over it is exactly 1, so the sub-layer output is W_o(W_v enc + b_v) + b_o
             # for every position, whatever the query (reference transformer.py:13-22 with Tk = 1)
@@ -171,7 +174,8 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
                 c.cc = ops.linear(c.v2, ca.W_o.weight, ca.W_o.bias)                    # [B,E]
             c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(c.cc, c.x1, ly.norm2.weight, ly.norm2.bias, p,
                                                              sd + _SITE, x_div=T, rows_dev=rows,
-                                                             x_map=None if ragged is None else ragged.sample)
+                                                             x_map=None if ragged is None else ragged.sample,
+                                                             seed_dev=seed_dev)
         else:
             c.q2 = ops.linear(c.x1, ca.W_q.weight, ca.W_q.bias, rows_dev=rows)
             kv2 = torch.empty((2, B * S, E), device=x.device, dtype=torch.float32)
@@ -184,11 +188,11 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None):
                 c.ao2, c.lse2 = ops.attention(c.q2, kv2[0], kv2[1], B, H, T, S, want_lse=True)
             a2 = ops.linear(c.ao2, ca.W_o.weight, ca.W_o.bias, rows_dev=rows)
             c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(a2, c.x1, ly.norm2.weight, ly.norm2.bias, p, sd + _SITE,
-                                                             rows_dev=rows)
+                                                             rows_dev=rows, seed_dev=seed_dev)
         c.h = ops.linear(c.x2, ff.fc1.weight, ff.fc1.bias, relu=True, rows_dev=rows)
         f = ops.linear(c.h, ff.fc2.weight, ff.fc2.bias, rows_dev=rows)
         x, c.s3, c.m3, c.r3 = ops.add_layernorm_train(f, c.x2, ly.norm3.weight, ly.norm3.bias, p, sd + 2 * _SITE,
-                                                      rows_dev=rows)
+                                                      rows_dev=rows, seed_dev=seed_dev)
         t.layers.append(c)
     t.out = x
     return x, t
@@ -213,14 +217,16 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         d_x2, d_f = ops.layernorm_bwd(dx, c.s3, c.m3, c.r3, ly.norm3.weight, p, sd + 2 * _SITE,
                                       _new(grads, pre + "norm3.weight", ly.norm3.weight),
                                       _new(grads, pre + "norm3.bias", ly.norm3.bias),
-                                      dxsum=_new(grads, pre + "feed_forward.fc2.bias", ff.fc2.bias), rows_dev=rows)
+                                      dxsum=_new(grads, pre + "feed_forward.fc2.bias", ff.fc2.bias), rows_dev=rows,
+                                      seed_dev=t.seed_dev)
         dh = _lin_bwd(grads, pre + "feed_forward.fc2", ff.fc2, d_f, c.h, mask=c.h, bias_done=True, rows=rows)   # ReLU backward fused
         _lin_bwd(grads, pre + "feed_forward.fc1", ff.fc1, dh, c.x2, accum=d_x2, rows=rows)
         # x2 = LN2(x1 + drop(a2)),  a2 = attn(x1 Wq, enc Wk, enc Wv) Wo
         d_x1, d_a2 = ops.layernorm_bwd(d_x2, c.s2, c.m2, c.r2, ly.norm2.weight, p, sd + _SITE,
                                        _new(grads, pre + "norm2.weight", ly.norm2.weight),
                                        _new(grads, pre + "norm2.bias", ly.norm2.bias),
-                                       dxsum=_new(grads, pre + "cross_attn.W_o.bias", ca.W_o.bias), rows_dev=rows)
+                                       dxsum=_new(grads, pre + "cross_attn.W_o.bias", ca.W_o.bias), rows_dev=rows,
+                                       seed_dev=t.seed_dev)
         if t.shortcut:
             def cross_constant_bwd():
                 d_cc = ops.group_sum(d_a2, T) if rg is None else ops.group_sum_segments(d_a2, rg.seq_off, B)   # [B,E]
@@ -257,7 +263,8 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         d_x, d_a = ops.layernorm_bwd(d_x1, c.s1, c.m1, c.r1, ly.norm1.weight, p, sd,
                                      _new(grads, pre + "norm1.weight", ly.norm1.weight),
                                      _new(grads, pre + "norm1.bias", ly.norm1.bias),
-                                     dxsum=_new(grads, pre + "self_attn.W_o.bias", sa.W_o.bias), rows_dev=rows)
+                                     dxsum=_new(grads, pre + "self_attn.W_o.bias", sa.W_o.bias), rows_dev=rows,
+                                     seed_dev=t.seed_dev)
         d_ao = _lin_bwd(grads, pre + "self_attn.W_o", sa.W_o, d_a, c.ao, bias_done=True, rows=rows)
         if rg is not None:
             dq, dk, dv = ops.attention_bwd_ragged(c.qkv[0], c.qkv[1], c.qkv[2], d_ao, c.lse, rg, H)
@@ -271,7 +278,7 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         if on_layer_done is not None:
             on_layer_done(l)          # every gradient of layer l is now enqueued
     if p > 0:
-        dx = ops.dropout(dx, p, t.seed)
+        dx = ops.dropout(dx, p, t.seed, seed_dev=t.seed_dev)
     ops.embed_bwd(t.ids.view(-1) if rg is None else t.ids_c, dx,
                   _new(grads, "decoder_embedding.weight", dec.decoder_embedding.weight), rows_dev=rows)
     if side_used and need_denc:
@@ -354,15 +361,15 @@ def vocab_loss_bwd(dec, x, saved, grads):
 # ---------------------------------------------------------------------------------------------
 # feature heads: Linear -> dropout -> BatchNorm1d (training statistics)
 # ---------------------------------------------------------------------------------------------
-def head_forward(model, parts, x, dropout_first, seed):
+def head_forward(model, parts, x, dropout_first, seed, seed_dev=None):
     """Training-mode head; returns (y [B, n*E], tape).  Updates the BatchNorm running buffers in place."""
     bn = model.batchnorm
     p = model.dropout.p
     t = Tape()
-    t.parts, t.p, t.seed, t.dropout_first = parts, p, seed, dropout_first
+    t.parts, t.p, t.seed, t.dropout_first, t.seed_dev = parts, p, seed, dropout_first, seed_dev
     xin = x.contiguous()
     if dropout_first and p > 0:
-        xin = ops.dropout(xin, p, seed)
+        xin = ops.dropout(xin, p, seed, seed_dev=seed_dev)
     t.xin = xin
     B = x.shape[0]
     E = parts[0][0].weight.shape[0]
@@ -371,7 +378,7 @@ def head_forward(model, parts, x, dropout_first, seed):
     for n, (fc, lo, hi) in enumerate(parts):
         ops.linear(xin[:, lo:hi], fc.weight, fc.bias, out=z[:, n * E:(n + 1) * E], split_k=(hi - lo >= 8192))
     if not dropout_first and p > 0:
-        z = ops.dropout(z, p, seed)
+        z = ops.dropout(z, p, seed, seed_dev=seed_dev)
     t.z = z
     momentum = 0.1 if bn.momentum is None else bn.momentum
     y, t.mean, t.rstd = ops.bn_train_forward(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps)
@@ -385,7 +392,7 @@ def head_backward(model, names, t, dy, grads):
     dz = ops.bn_train_backward(dy.contiguous(), t.z, bn.weight, t.mean, t.rstd,
                                _new(grads, "batchnorm.weight", bn.weight), _new(grads, "batchnorm.bias", bn.bias))
     if not t.dropout_first and t.p > 0:
-        dz = ops.dropout(dz, t.p, t.seed)
+        dz = ops.dropout(dz, t.p, t.seed, seed_dev=t.seed_dev)
     E = t.parts[0][0].weight.shape[0]
     for n, (fc, lo, hi) in enumerate(t.parts):
         _lin_bwd(grads, names[n], fc, dz[:, n * E:(n + 1) * E], t.xin[:, lo:hi], need_dx=False)
@@ -477,7 +484,7 @@ def _lstm_w(rnn):
     return (rnn.lstm.weight_ih_l0, rnn.lstm.weight_hh_l0, rnn.lstm.bias_ih_l0, rnn.lstm.bias_hh_l0)
 
 
-def rnn_forward(rnn, x0, ids, p, seed):
+def rnn_forward(rnn, x0, ids, p, seed, seed_dev=None):
     """LSTM over [image projection x0, dropout(embed(ids))] from the zero state, keeping what the backward
     needs.  Everything is stored time-major (row = step * B + sample) so that every step is a contiguous
     [B, .] block and the weight gradients are single contractions over all steps.
@@ -488,7 +495,7 @@ def rnn_forward(rnn, x0, ids, p, seed):
     Hd = w_hh.shape[1]
     dev = x0.device
     t = Tape()
-    t.B, t.T, t.E, t.Hd, t.p, t.seed = B, T, E, Hd, p, seed
+    t.B, t.T, t.E, t.Hd, t.p, t.seed, t.seed_dev = B, T, E, Hd, p, seed, seed_dev
     t.ids_tm = ids.t().contiguous()                                   # [T,B]
     n = (T + 1) * B
     t.x = torch.empty((n, E), device=dev, dtype=torch.float32)
@@ -498,7 +505,7 @@ def rnn_forward(rnn, x0, ids, p, seed):
     t.x[:B].copy_(x0)
     if T > 0:
         if p > 0:
-            ops.dropout(ops.embed_pe(t.ids_tm, rnn.embed.weight, None), p, seed, out=t.x[B:])
+            ops.dropout(ops.embed_pe(t.ids_tm, rnn.embed.weight, None), p, seed, out=t.x[B:], seed_dev=seed_dev)
         else:
             ops.embed_pe(t.ids_tm, rnn.embed.weight, None, out=t.x[B:])
     lib_step = ops.lstm_step_into
@@ -533,7 +540,7 @@ def rnn_backward(rnn, t, dh_out, grads):
     if T > 0:
         demb = dx[B:]
         if t.p > 0:
-            demb = ops.dropout(demb, t.p, t.seed)
+            demb = ops.dropout(demb, t.p, t.seed, seed_dev=t.seed_dev)
         ops.embed_bwd(t.ids_tm.view(-1), demb, _new(grads, "embed.weight", rnn.embed.weight))
     else:
         _new(grads, "embed.weight", rnn.embed.weight)

@@ -374,17 +374,23 @@ def group_sum(x, T):
     return out
 
 
-def dropout(x, p, seed, out=None):
+def _seed_ptr(seed_dev):
+    """Device address of the per-step seed (an int64 tensor whose first element is added to the by-value seed)."""
+    return None if seed_dev is None else _chk(seed_dev, torch.int64, "seed_dev").data_ptr()
+
+
+def dropout(x, p, seed, out=None, seed_dev=None):
     lib = _lib.load()
     if not x.is_contiguous():
         raise RuntimeError("capdec dropout: x must be contiguous")
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(lib.capdec_dropout(_chk(x).data_ptr(), x.numel(), p, seed, out.data_ptr(), _stream()), "capdec_dropout")
+    _lib.check(lib.capdec_dropout(_chk(x).data_ptr(), x.numel(), p, seed, _seed_ptr(seed_dev), out.data_ptr(), _stream()),
+               "capdec_dropout")
     return out
 
 
-def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5, x_div=1, x_map=None, rows_dev=None):
+def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5, x_div=1, x_map=None, rows_dev=None, seed_dev=None):
     """s = add + dropout(x); y = LN(s).  Returns (y, s, mean, rstd).  With x_div > 1, x holds one row per
     ``x_div`` consecutive rows of ``add`` (a per-sample row broadcast over its positions); with x_map (int32 [M]) row r
     takes x[x_map[r]].  rows_dev: int32 device scalar, only the first rows_dev[0] rows are processed."""
@@ -404,13 +410,14 @@ def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5, x_div=1, x_map=N
     _lib.check(lib.capdec_add_layernorm_train_rows(_chk(x).data_ptr(), x_div,
                                                    None if x_map is None else _chk(x_map, torch.int32, "x_map").data_ptr(),
                                                    _chk(add).data_ptr(), _chk(gamma).data_ptr(), _chk(beta).data_ptr(),
-                                                   eps, M, E, p, seed, y.data_ptr(), s.data_ptr(), mean.data_ptr(),
+                                                   eps, M, E, p, seed, _seed_ptr(seed_dev), y.data_ptr(), s.data_ptr(),
+                                                   mean.data_ptr(),
                                                    rstd.data_ptr(), _ptr(rows_dev), _stream()),
                "capdec_add_layernorm_train_rows")
     return y, s, mean, rstd
 
 
-def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None, rows_dev=None):
+def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None, rows_dev=None, seed_dev=None):
     """Returns (d_add, d_x); dgamma/dbeta are accumulated, and so are the column sums of d_x into ``dxsum`` [E]
     when given (the bias gradient of the linear layer whose output was normalised)."""
     lib = _lib.load()
@@ -420,7 +427,8 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None, 
     d_add = torch.empty((M, E), device=dy.device, dtype=torch.float32)
     d_x = torch.empty_like(d_add) if p > 0 else None
     _lib.check(lib.capdec_layernorm_bwd_rows(_chk(dy).data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                             _chk(gamma).data_ptr(), M, E, p, seed, d_add.data_ptr(), _ptr(d_x),
+                                             _chk(gamma).data_ptr(), M, E, p, seed, _seed_ptr(seed_dev), d_add.data_ptr(),
+                                             _ptr(d_x),
                                              _chk(dgamma).data_ptr(), _chk(dbeta).data_ptr(), _ptr(dxsum),
                                              _ptr(rows_dev), _stream()), "capdec_layernorm_bwd_rows")
     return d_add, (d_x if p > 0 else d_add)
@@ -612,3 +620,47 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale
             raise RuntimeError("capdec adam_step: flat contiguous buffers of equal length expected")
     _lib.check(lib.capdec_adam_step(_chk(p).data_ptr(), _chk(g).data_ptr(), _chk(m).data_ptr(), _chk(v).data_ptr(),
                                     p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()), "capdec_adam_step")
+
+
+class TrainState:
+    """capdec_train_state in device memory (32 bytes): dropout seed of the step, Adam's step count and bias corrections,
+    learning rate.  ``seed_dev`` is the tensor to hand to the dropout-drawing wrappers."""
+
+    def __init__(self, device, lr, seed, step=0):
+        self.buf = torch.zeros(4, dtype=torch.int64, device=device)
+        self.seed_dev = self.buf[:1]
+        self._i32 = self.buf.view(torch.int32)        # [seed lo, seed hi, step, lr bits, bias1, bias2_sqrt, -, -]
+        self._f32 = self.buf.view(torch.float32)
+        self.set(seed=seed, step=step, lr=lr)
+
+    def set(self, seed=None, step=None, lr=None):
+        """Host-side writes (outside any captured graph): tiny device copies on the current stream."""
+        if seed is not None:
+            self.buf[0] = int(seed) & (2 ** 62 - 1)
+        if step is not None:
+            self._i32[2] = int(step)
+            # bias corrections of `step` itself, for a caller that reads them before the next advance
+        if lr is not None:
+            self._f32[3] = float(lr)
+
+    def advance(self, beta1, beta2):
+        lib = _lib.load()
+        _lib.check(lib.capdec_train_state_advance(self.buf.data_ptr(), beta1, beta2, _stream()),
+                   "capdec_train_state_advance")
+
+    def read(self):
+        """(seed, step, lr, bias1, bias2_sqrt) -- synchronises; for tests and checkpoints."""
+        h = self.buf.cpu()
+        return (int(h[0]), int(h.view(torch.int32)[2]), float(h.view(torch.float32)[3]),
+                float(h.view(torch.float32)[4]), float(h.view(torch.float32)[5]))
+
+
+def adam_step_dev(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """Adam over flat buffers with lr / step count / bias corrections read from ``state`` (TrainState)."""
+    lib = _lib.load()
+    for t in (p, g, m, v):
+        if not t.is_contiguous() or t.numel() != p.numel():
+            raise RuntimeError("capdec adam_step_dev: flat contiguous buffers of equal length expected")
+    _lib.check(lib.capdec_adam_step_dev(_chk(p).data_ptr(), _chk(g).data_ptr(), _chk(m).data_ptr(), _chk(v).data_ptr(),
+                                        p.numel(), beta1, beta2, eps, state.buf.data_ptr(), grad_scale, _stream()),
+               "capdec_adam_step_dev")

@@ -7,7 +7,10 @@ batch statistics).  Differences in mechanism, not in result:
   * parameters are views of one flat fp32 buffer and gradients of another, laid out in the order the
     backward pass completes them, so the gradient exchange is a handful of large RCCL all-reduces issued
     while the rest of the backward pass is still running, and Adam is one kernel over the flat buffers;
-  * the [B*T, V] logits are never materialised in the forward pass (fused log-sum-exp + NLL).
+  * the per-step scalars (dropout seed, Adam's step count and bias corrections, learning rate) live in device
+    memory (``ops.TrainState``) and are advanced by a kernel, so a step has no per-step kernel arguments and the whole
+    of it -- forward, loss, backward, Adam -- can be captured once in a HIP graph and replayed (``graph=True``): one
+    host call per step instead of ~150 kernel launches from Python, which is what bounds small per-GPU batches.
 """
 import os
 
@@ -17,6 +20,7 @@ import torch.distributed as dist
 from . import autograd as AG
 from . import dist as cdist
 from . import ops
+from .autograd import Tape
 
 
 def _head_spec(model):
@@ -34,27 +38,37 @@ def _head_spec(model):
 class CaptionTrainer:
     """One object per process (one process per GPU)."""
 
+    # by-value parts of the dropout seeds: they tell the sites of one step apart (the per-step part is on the device)
+    _SEED_HEAD, _SEED_DECODER = 0x2545F4914F6CDD1D, 0
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, pad_idx=0, overlap=True,
-                 skip_dead_rows=True, wgrad_stream=None):
+                 skip_dead_rows=True, wgrad_stream=None, graph=False):
         """overlap=True: one async all-reduce per gradient segment, issued as soon as the backward pass has enqueued
         that segment; overlap=False: a single all-reduce of the whole flat gradient buffer after the backward pass.
         skip_dead_rows: run the Transformer stack on the live prefix of every caption only (the positions from a
         caption's last counted target on feed nothing but ignored loss terms); same loss and gradients, the dropout
         masks are drawn per live row.  Applies where ``autograd.ragged_supported`` holds, else the full rows run.
         wgrad_stream: run the weight-gradient contractions on a second HIP stream beside the input-gradient chain
-        (default on; the environment variable CAPDEC_WGRAD_STREAM=0 switches it off when the argument is None)."""
+        (default on; the environment variable CAPDEC_WGRAD_STREAM=0 switches it off when the argument is None).
+        graph: capture the step in a HIP graph.  The first step with a given input shape runs launch by launch (it
+        also lets every kernel variant do its one-time set-up), the second is captured and replayed, later ones are
+        replays (inputs are copied into fixed buffers first).  Same kernels in the same order as the launch-by-launch step, hence the
+        same losses and parameters.  With more than one rank the gradient exchange stays outside the graph: forward +
+        backward replay as one graph, then one all-reduce of the flat gradient buffer, then Adam."""
         self.model = model
         self.overlap = overlap
         self.skip_dead_rows = skip_dead_rows
         self._want_side = (os.environ.get("CAPDEC_WGRAD_STREAM", "1") == "1") if wgrad_stream is None else bool(wgrad_stream)
         self.side_stream = None
-        self.lr, self.betas, self.eps, self.pad_idx = lr, betas, eps, pad_idx
+        self.betas, self.eps, self.pad_idx = betas, eps, pad_idx
+        self.graph = bool(graph)
+        self._graphs = {}              # input shapes -> None (seen once, run eagerly) | captured step
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         # gloo has no dependable device collectives: stage through the host there (tests and rehearsals on one GPU);
         # RCCL ("nccl") reduces the device buffers in place
         self.host_staged = self.world > 1 and dist.get_backend(process_group) == "gloo"
-        self.t = 0
+        self._t, self._lr = 0, float(lr)
         self.rnn = getattr(model, "decoderRNN", None)          # CNN-RNN: the trainable module is the LSTM decoder
         core = self.rnn if self.rnn is not None else model
         self.core = core
@@ -64,6 +78,8 @@ class CaptionTrainer:
             raise RuntimeError("capdec: the trainer needs the model on the GPU (HIP); there is no CPU path")
         if self._want_side:
             self.side_stream = torch.cuda.Stream(device=dev)
+        # the first step's seed comes from torch's CPU generator, so torch.manual_seed makes a run repeatable
+        self.state = ops.TrainState(dev, self._lr, AG.draw_seed(), 0)
         # segments in the order the backward pass finishes them
         seg_names = [[n for n in named if n.startswith("fc2.")]]
         if self.rnn is not None:
@@ -123,27 +139,57 @@ class CaptionTrainer:
             cdist.broadcast_(t, src=0, group=self.pg)
 
     def _reduce_segment(self, i, works):
-        if self.world > 1 and self.overlap:
+        if self._reduce_on:
             AG.join_side_stream()                      # the segment's weight gradients may still be in flight there
             a, b = self.segments[i]
-            if self.host_staged:
-                h = self.flat_g[a:b].cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
-                self.flat_g[a:b].copy_(h)
-            else:
-                works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            try:
+                if self.host_staged:
+                    h = self.flat_g[a:b].cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+                    self.flat_g[a:b].copy_(h)
+                else:
+                    works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            except Exception as e:
+                raise RuntimeError(f"capdec: gradient all-reduce failed on rank {dist.get_rank(self.pg)}, segment {i} "
+                                   f"of {len(self.segments)} (elements {a}:{b}): {e}") from e
 
-    def step(self, feats, captions):
-        """feats: precomputed backbone features [B,D]; captions [B,T+1] int64 (inputs [:, :-1], targets [:, 1:]).
-        Returns the rank-local loss as a 1-element device tensor (no host sync)."""
-        model = self.model
-        model.train()
-        self.t += 1
+    def _wait(self, works):
+        for i, w in enumerate(works):
+            try:
+                w.wait()
+            except Exception as e:
+                raise RuntimeError(f"capdec: gradient all-reduce failed on rank {dist.get_rank(self.pg)} while waiting "
+                                   f"for segment {i} of {len(self.segments)}: {e}") from e
+
+    # ---- per-step scalars: host shadows of the device state ---------------------------------------------
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        self.state.set(lr=self._lr)
+
+    @property
+    def t(self):
+        """Number of optimizer steps taken (Adam's step count)."""
+        return self._t
+
+    @t.setter
+    def t(self, value):
+        self._t = int(value)
+        self.state.set(step=self._t)
+
+    # ---- one step --------------------------------------------------------------------------------------------
+    def _forward_backward(self, feats, captions, reduce_inside):
+        """Everything of a step up to, not including, the optimizer: state advance, zeroed gradients, forward, loss,
+        backward.  reduce_inside: issue the per-segment all-reduces while the backward pass is enqueued."""
+        self.state.advance(self.betas[0], self.betas[1])
         self.flat_g.zero_()
-        if self.world > 1:
-            self._bcast(self.flat_buf)
         ids = captions[:, :-1].contiguous()
         tgt = captions[:, 1:].contiguous()
+        self._reduce_on = reduce_inside
         AG.use_side_stream(self.side_stream)
         try:
             if self.rnn is not None:
@@ -153,24 +199,77 @@ class CaptionTrainer:
             AG.join_side_stream()
         finally:
             AG.use_side_stream(None)
-        if self.world > 1 and not self.overlap:
+        return loss
+
+    def _all_reduce_whole(self):
+        try:
             if self.host_staged:
                 h = self.flat_g.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
                 self.flat_g.copy_(h)
             else:
                 dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
-        # ---- Adam over the flat buffers (DDP semantics: mean of the per-rank gradients) ----
-        ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1],
-                      self.eps, grad_scale=1.0 / self.world)
+        except Exception as e:
+            raise RuntimeError(f"capdec: gradient all-reduce failed on rank {dist.get_rank(self.pg)} "
+                               f"(whole buffer, {self.flat_g.numel() * 4} bytes): {e}") from e
+
+    def _adam(self):
+        # DDP semantics: mean of the per-rank gradients
+        ops.adam_step_dev(self.flat_p, self.flat_g, self.m, self.v, self.state, self.betas[0], self.betas[1], self.eps,
+                          grad_scale=1.0 / self.world)
+
+    def step(self, feats, captions):
+        """feats: precomputed backbone features [B,D]; captions [B,T+1] int64 (inputs [:, :-1], targets [:, 1:]).
+        Returns the rank-local loss as a 1-element device tensor (no host sync)."""
+        self.model.train()
+        self._t += 1
+        if self.world > 1:
+            self._bcast(self.flat_buf)
+        if self.graph:
+            return self._graph_step(feats, captions)
+        loss = self._forward_backward(feats, captions, reduce_inside=self.world > 1 and self.overlap)
+        if self.world > 1 and not self.overlap:
+            self._all_reduce_whole()
+        self._adam()
+        return loss
+
+    def _graph_step(self, feats, captions):
+        key = (tuple(feats.shape), tuple(captions.shape), feats.dtype, captions.dtype)
+        if key not in self._graphs:
+            # first sight of this shape: launch by launch (a real step; also every kernel variant's one-time set-up)
+            self._graphs[key] = None
+            loss = self._forward_backward(feats, captions, reduce_inside=False)
+            if self.world > 1:
+                self._all_reduce_whole()
+            self._adam()
+            return loss
+        cap = self._graphs[key]
+        if cap is None:
+            cap = Tape()
+            cap.feats = torch.empty_like(feats)
+            cap.captions = torch.empty_like(captions)
+            cap.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cap.graph):
+                cap.loss = self._forward_backward(cap.feats, cap.captions, reduce_inside=False)
+                if self.world == 1:
+                    self._adam()
+            self._graphs[key] = cap
+        cap.feats.copy_(feats)
+        cap.captions.copy_(captions)
+        cap.graph.replay()
+        loss = cap.loss.clone()            # the graph writes the same storage at every replay
+        if self.world > 1:
+            self._all_reduce_whole()
+            self._adam()
         return loss
 
     def _rnn_step(self, feats, ids, tgt):
         """CNN-RNN (reference cnnrnn_model.py:20-34): dropout -> fc1 -> BatchNorm, LSTM over [image, captions]."""
         rnn = self.rnn
         p = rnn.dropout.p
-        x0, htape = AG.head_forward(rnn, [(rnn.fc1, 0, feats.shape[1])], feats, True, AG.draw_seed() if p > 0 else 0)
-        h, tape = AG.rnn_forward(rnn, x0, ids, p, AG.draw_seed() if p > 0 else 0)
+        sdev = self.state.seed_dev
+        x0, htape = AG.head_forward(rnn, [(rnn.fc1, 0, feats.shape[1])], feats, True, self._SEED_HEAD, seed_dev=sdev)
+        h, tape = AG.rnn_forward(rnn, x0, ids, p, self._SEED_DECODER, seed_dev=sdev)
         loss, saved = AG.vocab_loss(rnn, h, tgt.t().contiguous(), self.pad_idx)      # rows of h are time-major
         works = []
         dh = AG.vocab_loss_bwd(rnn, h, saved, self.grads)
@@ -179,8 +278,7 @@ class CaptionTrainer:
         self._reduce_segment(1, works)
         AG.head_backward(rnn, ["fc1"], htape, dx0, self.grads)
         self._reduce_segment(2, works)
-        for w in works:
-            w.wait()
+        self._wait(works)
         return loss
 
     def _tf_step(self, feats, ids, tgt):
@@ -192,13 +290,14 @@ class CaptionTrainer:
         if self.fc_b:
             parts.append((getattr(model, self.fc_b), self.split, feats.shape[1]))
             names.append(self.fc_b)
-        y, htape = AG.head_forward(model, parts, feats, False, AG.draw_seed() if p > 0 else 0)
+        sdev = self.state.seed_dev
+        y, htape = AG.head_forward(model, parts, feats, False, self._SEED_HEAD, seed_dev=sdev)
         B = feats.shape[0]
         enc = y.view(B, len(parts), -1)
         rg = None
         if self.skip_dead_rows and AG.ragged_supported(model, enc.shape[1], ids.shape[1], B):
             rg = ops.RaggedRows(ids, tgt, self.pad_idx)
-        x, tape = AG.tf_forward(model, enc, ids, p, AG.draw_seed() if p > 0 else 0, ragged=rg)
+        x, tape = AG.tf_forward(model, enc, ids, p, self._SEED_DECODER, ragged=rg, seed_dev=sdev)
         if rg is not None:
             loss, saved = AG.vocab_loss(model, x, rg.targets_c, self.pad_idx, rows=rg.rows)
         else:
@@ -209,19 +308,18 @@ class CaptionTrainer:
         self._reduce_segment(0, works)
         denc = AG.tf_backward(model, tape, dx, self.grads, need_denc=True,
                               on_layer_done=(lambda l: self._reduce_segment(len(model.decoder_layers) - l, works))
-                              if self.world > 1 else None)
+                              if self._reduce_on else None)
         self._reduce_segment(len(self.segments) - 2, works)          # embedding
         AG.head_backward(model, names, htape, denc.reshape(B, -1), self.grads)
         self._reduce_segment(len(self.segments) - 1, works)          # head
-        for w in works:
-            w.wait()
+        self._wait(works)
         return loss
 
     def scheduler_step(self, epoch, step_size=5, gamma=0.8):
         """``StepLR(step_size=5, gamma=0.8)`` stepped once per epoch (reference train.py:218,366): call after epoch
         number ``epoch`` (0-based) has finished; returns the learning rate of the next epoch."""
         if (epoch + 1) % step_size == 0:
-            self.lr *= gamma
+            self.lr = self.lr * gamma          # the setter also writes the device-resident value the Adam kernel reads
         return self.lr
 
     def grad_bytes(self):

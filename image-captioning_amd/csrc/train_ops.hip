@@ -32,12 +32,18 @@ __device__ __forceinline__ f32x4 drop_scale4(uint64_t seed, uint64_t idx0, float
     return r;
 }
 
-__global__ void dropout_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed, float* __restrict__ y) {
+// seed_dev (nullable): a device-resident seed added to the by-value one, so that a step captured in a HIP graph draws
+// new masks at every replay (the by-value part then only tells the dropout sites of one step apart)
+__global__ void dropout_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed,
+                               const uint64_t* __restrict__ seed_dev, float* __restrict__ y) {
+    if (seed_dev) seed += seed_dev[0];
     const float inv_keep = 1.0f / (1.0f - p);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = x[i] * drop_scale(seed, (uint64_t)i, p, inv_keep);
 }
-__global__ void dropout4_kernel(const f32x4* __restrict__ x, int64_t n4, float p, uint64_t seed, f32x4* __restrict__ y) {
+__global__ void dropout4_kernel(const f32x4* __restrict__ x, int64_t n4, float p, uint64_t seed,
+                                const uint64_t* __restrict__ seed_dev, f32x4* __restrict__ y) {
+    if (seed_dev) seed += seed_dev[0];
     const float inv_keep = 1.0f / (1.0f - p);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = x[i] * drop_scale4(seed, (uint64_t)i * 4, p, inv_keep);
@@ -71,7 +77,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int M, int E,
-                                                           int x_div, float p, uint64_t seed, float* __restrict__ y,
+                                                           int x_div, float p, uint64_t seed,
+                                                           const uint64_t* __restrict__ seed_dev, float* __restrict__ y,
                                                            float* __restrict__ s_out, float* __restrict__ mean_out,
                                                            float* __restrict__ rstd_out,
                                                            const int32_t* __restrict__ x_map,
@@ -79,6 +86,7 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M || (rows_dev && row >= rows_dev[0])) return;
+    if (seed_dev) seed += seed_dev[0];
     const int nv = E / 4;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)(x_map ? x_map[row] : row / x_div) * E);
     const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (int64_t)row * E) : nullptr;
@@ -140,12 +148,14 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int M, int E, float p,
-                                                     uint64_t seed, float* __restrict__ d_add, float* __restrict__ d_x,
+                                                     uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                     float* __restrict__ d_add, float* __restrict__ d_x,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      float* __restrict__ dxsum, const int32_t* __restrict__ rows_dev) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][3][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (rows_dev) M = min(M, rows_dev[0]);
+    if (seed_dev) seed += seed_dev[0];
     if ((int)blockIdx.x * LNB_ROWS >= M) return;
     const int nv = E / 4;
     const float inv_keep = 1.0f / (1.0f - p);
@@ -838,6 +848,36 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// The same with step size and bias corrections read from the device-resident training state, so that the launch
+// has no per-step arguments and can sit in a captured graph.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, int64_t n, float b1, float b2, float eps,
+                                const capdec_train_state* __restrict__ st, float gscale) {
+    const float lr = st->lr, bc1 = st->bias1, bc2_sqrt = st->bias2_sqrt;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+// One thread: next optimizer step.  step += 1; a new dropout seed (splitmix64 of the old one); Adam's bias corrections
+// for the new step count.
+__global__ void train_state_advance_kernel(capdec_train_state* __restrict__ st, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int t = st->step + 1;
+    uint64_t z = st->seed + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    st->seed = (z ^ (z >> 31)) >> 2;                 // 62 bits: the by-value site offsets cannot overflow the sum
+    st->step = t;
+    st->bias1 = (float)(1.0 - pow((double)b1, (double)t));
+    st->bias2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+
 // loss = sum nll / n valid ; gscale = 1 / n valid  (CrossEntropyLoss(ignore_index) mean reduction)
 __global__ void loss_finish_kernel(const float* __restrict__ sums, float* __restrict__ loss, float* __restrict__ gscale) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1183,14 +1223,15 @@ __global__ __launch_bounds__(1024) void compact_prefix_kernel(const int64_t* __r
 
 extern "C" {
 
-int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, void* stream) {
+int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, float* y, void* stream) {
     CAPDEC_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f);
     if (n == 0) return 0;
     if (n % 4 == 0 && capdec_aligned16(x) && capdec_aligned16(y))
         hipLaunchKernelGGL(dropout4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const f32x4*>(x), n / 4, p, seed, reinterpret_cast<f32x4*>(y));
+                           reinterpret_cast<const f32x4*>(x), n / 4, p, seed, seed_dev, reinterpret_cast<f32x4*>(y));
     else
-        hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, p, seed, y);
+        hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, p, seed, seed_dev,
+                           y);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -1198,13 +1239,14 @@ int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, 
 int capdec_add_layernorm_train(const float* x, int x_div, const float* add, const float* gamma, const float* beta,
                                float eps, int M, int E, float p, uint64_t seed, float* y, float* s_out, float* mean,
                                float* rstd, void* stream) {
-    return capdec_add_layernorm_train_rows(x, x_div, nullptr, add, gamma, beta, eps, M, E, p, seed, y, s_out, mean, rstd,
-                                           nullptr, stream);
+    return capdec_add_layernorm_train_rows(x, x_div, nullptr, add, gamma, beta, eps, M, E, p, seed, nullptr, y, s_out, mean,
+                                           rstd, nullptr, stream);
 }
 
 int capdec_add_layernorm_train_rows(const float* x, int x_div, const int32_t* x_map, const float* add, const float* gamma,
-                                    const float* beta, float eps, int M, int E, float p, uint64_t seed, float* y,
-                                    float* s_out, float* mean, float* rstd, const int32_t* rows_dev, void* stream) {
+                                    const float* beta, float eps, int M, int E, float p, uint64_t seed,
+                                    const uint64_t* seed_dev, float* y, float* s_out, float* mean, float* rstd,
+                                    const int32_t* rows_dev, void* stream) {
     CAPDEC_REQUIRE(x && gamma && beta && y && M >= 0 && E >= 4 && E % 4 == 0 && E <= 256 * LN_MAXV && p >= 0.f && p < 1.f);
     CAPDEC_REQUIRE(x_div >= 1);
     if (!capdec_aligned16(x) || !capdec_aligned16(y) || !capdec_aligned16(gamma) || !capdec_aligned16(beta) ||
@@ -1213,7 +1255,7 @@ int capdec_add_layernorm_train_rows(const float* x, int x_div, const int32_t* x_
     if (M == 0) return 0;
 #define CAPDEC_CALL(NV_)                                                                                          \
     hipLaunchKernelGGL(ln_train_fwd_kernel<NV_>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add, gamma, \
-                       beta, eps, M, E, x_div, p, seed, y, s_out, mean, rstd, x_map, rows_dev)
+                       beta, eps, M, E, x_div, p, seed, seed_dev, y, s_out, mean, rstd, x_map, rows_dev)
     CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
@@ -1223,13 +1265,13 @@ int capdec_add_layernorm_train_rows(const float* x, int x_div, const int32_t* x_
 int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                          int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma, float* dbeta,
                          float* dxsum, void* stream) {
-    return capdec_layernorm_bwd_rows(dy, s, mean, rstd, gamma, M, E, p, seed, d_add, d_x, dgamma, dbeta, dxsum, nullptr,
-                                     stream);
+    return capdec_layernorm_bwd_rows(dy, s, mean, rstd, gamma, M, E, p, seed, nullptr, d_add, d_x, dgamma, dbeta, dxsum,
+                                     nullptr, stream);
 }
 
 int capdec_layernorm_bwd_rows(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
-                              int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma,
-                              float* dbeta, float* dxsum, const int32_t* rows_dev, void* stream) {
+                              int M, int E, float p, uint64_t seed, const uint64_t* seed_dev, float* d_add, float* d_x,
+                              float* dgamma, float* dbeta, float* dxsum, const int32_t* rows_dev, void* stream) {
     CAPDEC_REQUIRE(dy && s && mean && rstd && gamma && dgamma && dbeta && M >= 0 && E >= 4 && E % 4 == 0 &&
                    E <= 256 * LN_MAXV && p >= 0.f && p < 1.f);
     if (!capdec_aligned16(dy) || !capdec_aligned16(s) || !capdec_aligned16(gamma) || (d_add && !capdec_aligned16(d_add)) ||
@@ -1242,7 +1284,7 @@ int capdec_layernorm_bwd_rows(const float* dy, const float* s, const float* mean
     if (!wide_ok) return CAPDEC_EINVAL;
 #define CAPDEC_CALL(NV_)                                                                                           \
     hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 12 * E * sizeof(float),    \
-                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, d_add, d_x, dgamma, dbeta, dxsum, rows_dev)
+                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, seed_dev, d_add, d_x, dgamma, dbeta, dxsum, rows_dev)
     CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
@@ -1553,6 +1595,23 @@ int capdec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
     const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                        beta2, eps, bc1, bc2_sqrt, grad_scale);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_train_state_advance(capdec_train_state* st, float beta1, float beta2, void* stream) {
+    CAPDEC_REQUIRE(st && beta1 > 0.f && beta1 < 1.f && beta2 > 0.f && beta2 < 1.f);
+    hipLaunchKernelGGL(train_state_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, st, beta1, beta2);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                         const capdec_train_state* st, float grad_scale, void* stream) {
+    CAPDEC_REQUIRE(p && g && m && v && st && n >= 0);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2,
+                       eps, st, grad_scale);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

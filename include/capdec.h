@@ -195,7 +195,11 @@ int capdec_bn_train_forward(const float* x, const float* gamma, const float* bet
  * regenerates the mask from the same seed, nothing is stored.  Column-reduced gradients (dgamma, dbeta,
  * bias and embedding gradients) are ACCUMULATED into their outputs with float atomics: zero them first.
  * ------------------------------------------------------------------------------------------ */
-int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, float* y, void* stream);
+/* seed_dev (nullable, here and below): a device-resident 64-bit value that the kernel ADDS to `seed` when it starts.  A
+ * training step captured in a HIP graph keeps its by-value arguments for ever; with the per-step part of the seed in
+ * device memory (capdec_train_state.seed, advanced by a kernel inside the graph) every replay draws new masks, and
+ * `seed` only tells the dropout sites of one step apart. */
+int capdec_dropout(const float* x, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, float* y, void* stream);
 /* s = add + dropout_p(x) ; y = LayerNorm(s) ; s_out/mean/rstd (nullable) are saved for the backward pass.
  * Row r of the sum reads row r / x_div of x (x_div = T broadcasts one row per sample over its T positions, the
  * single-memory-row cross-attention output); the dropout mask is still drawn per element of the [M,E] sum. */
@@ -205,8 +209,9 @@ int capdec_add_layernorm_train(const float* x, int x_div, const float* add, cons
 /* The same with the broadcast row taken from x_map (nullable: x row of output row r is x_map[r] instead of r / x_div)
  * and only the first rows_dev[0] rows processed (rows_dev: nullable device scalar). */
 int capdec_add_layernorm_train_rows(const float* x, int x_div, const int32_t* x_map, const float* add, const float* gamma,
-                                    const float* beta, float eps, int M, int E, float p, uint64_t seed, float* y,
-                                    float* s_out, float* mean, float* rstd, const int32_t* rows_dev, void* stream);
+                                    const float* beta, float eps, int M, int E, float p, uint64_t seed,
+                                    const uint64_t* seed_dev, float* y, float* s_out, float* mean, float* rstd,
+                                    const int32_t* rows_dev, void* stream);
 /* d_add = dLN/ds ; d_x = d_add * dropout mask (same p, seed as the forward) ; dgamma/dbeta accumulated;
  * dxsum (nullable, [E], accumulated): column sums of d_x = the bias gradient of the linear layer that produced x */
 int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
@@ -214,8 +219,8 @@ int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, con
                          float* dxsum, void* stream);
 /* The same over the first min(M, rows_dev[0]) rows (rows_dev: nullable device scalar). */
 int capdec_layernorm_bwd_rows(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
-                              int M, int E, float p, uint64_t seed, float* d_add, float* d_x, float* dgamma,
-                              float* dbeta, float* dxsum, const int32_t* rows_dev, void* stream);
+                              int M, int E, float p, uint64_t seed, const uint64_t* seed_dev, float* d_add, float* d_x,
+                              float* dgamma, float* dbeta, float* dxsum, const int32_t* rows_dev, void* stream);
 /* out[j] += sum_i x[i*ldx + j] */
 int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream);
 /* The same over the first min(M, rows_dev[0]) rows (rows_dev: nullable device scalar). */
@@ -296,6 +301,24 @@ int capdec_loss_finish(const float* sums, float* loss, float* gscale, void* stre
  * buffer; g is multiplied by grad_scale first (1/world for a summed all-reduce). */
 int capdec_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, int step, float grad_scale, void* stream);
+
+/* Per-step scalars of the training loop (train.py:217-218,244-262,366) held in DEVICE memory, so that a whole step --
+ * forward, loss, backward, Adam -- can be captured once in a HIP graph and replayed with no per-step kernel arguments:
+ * the dropout seed of the step, Adam's step count with its two bias corrections, and the learning rate (written by the
+ * host when StepLR changes it).  capdec_train_state_advance starts the next step: step += 1, seed = a new 62-bit value
+ * (splitmix64 of the old one), bias1 = 1 - beta1^step, bias2_sqrt = sqrt(1 - beta2^step) (computed in double).
+ * capdec_adam_step_dev is capdec_adam_step with lr and the corrections read from the state. */
+typedef struct capdec_train_state {
+    uint64_t seed;
+    int32_t step;
+    float lr;
+    float bias1;
+    float bias2_sqrt;
+    int32_t reserved[2];
+} capdec_train_state;   /* 32 bytes */
+int capdec_train_state_advance(capdec_train_state* st /*device*/, float beta1, float beta2, void* stream);
+int capdec_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                         const capdec_train_state* st /*device*/, float grad_scale, void* stream);
 
 /* One LSTM step, gate order i,f,g,o (nn.LSTM, cnnrnn_model.py:17,29-30,83):
  *   gates = x W_ih^T + b_ih + h W_hh^T + b_hh ; c' = s(f) c + s(i) tanh(g) ; h' = s(o) tanh(c')

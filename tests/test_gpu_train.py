@@ -374,6 +374,105 @@ def test_train_mode_with_dropout_runs_and_is_seeded():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in dec.parameters())
 
 
+def test_train_state_advance_and_adam_from_device_state():
+    """The device-resident per-step scalars: step count, bias corrections, learning rate and a fresh seed per step; Adam
+    reading them gives torch.optim.Adam's parameters."""
+    from capdec import ops
+    st = ops.TrainState(torch.device("cuda"), 1e-3, seed=12345, step=0)
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(5000, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.clone().cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    seeds = [st.read()[0]]
+    for step in range(1, 6):
+        if step == 4:                      # StepLR changed the rate: the host writes it, the kernel reads it
+            st.set(lr=5e-4)
+            opt.param_groups[0]["lr"] = 5e-4
+        st.advance(0.9, 0.999)
+        seed, t_dev, lr, b1, b2s = st.read()
+        assert t_dev == step and 0 <= seed < 2 ** 62 and seed not in seeds
+        seeds.append(seed)
+        f1, f2 = float(np.float32(0.9)), float(np.float32(0.999))      # the betas cross the C ABI as floats
+        assert abs(b1 - (1 - f1 ** step)) <= 1e-7 and abs(b2s - (1 - f2 ** step) ** 0.5) <= 1e-7
+        assert abs(lr - (5e-4 if step >= 4 else 1e-3)) <= 1e-10
+        grad = torch.randn(5000, generator=g)
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adam_step_dev(p, grad.cuda(), m, v, st)
+    close(p, ref.detach(), rtol=1e-6)
+    # the device seed is added to the by-value one: same sum, same mask
+    x = torch.ones(1 << 16, device="cuda")
+    assert torch.equal(ops.dropout(x, 0.3, 1000 + seeds[-1]), ops.dropout(x, 0.3, 1000, seed_dev=st.seed_dev))
+    assert not torch.equal(ops.dropout(x, 0.3, 1000), ops.dropout(x, 0.3, 1000, seed_dev=st.seed_dev))
+
+
+def test_graph_trainer_draws_new_dropout_masks_and_tracks_the_launched_trainer():
+    """Dropout on (p = 0.1), six steps on changing batches: a trainer whose step is captured in a HIP graph and one that
+    launches kernel by kernel start from the same weights and the same seed; they must see the same masks at every
+    step (the seed lives on the device and advances inside the graph), so losses agree to rounding, and the losses of
+    one batch fed twice must differ (new masks at every replay)."""
+    from capdec.trainer import CaptionTrainer
+    from models.vitattn_model import VITAttentionModel
+    E, V, H, L, B, T = 64, 150, 4, 2, 24, 11
+    torch.manual_seed(21)
+    a = VITAttentionModel(E, V, H, L, dropout=0.1).cuda()
+    b = VITAttentionModel(E, V, H, L, dropout=0.1).cuda()
+    b.load_state_dict(a.state_dict())
+    torch.manual_seed(22)
+    ta = CaptionTrainer(a, lr=1e-3, graph=False)
+    torch.manual_seed(22)
+    tb = CaptionTrainer(b, lr=1e-3, graph=True)
+    assert ta.state.read()[0] == tb.state.read()[0]
+    g = torch.Generator().manual_seed(23)
+    la, lb = [], []
+    for step in range(6):
+        if step in (0, 1, 2):       # step 1 and 2 reuse batch 0: a replay with the same inputs
+            if step == 0:
+                feats = torch.rand(B, 1000, generator=g).cuda()
+                caps = torch.randint(4, V, (B, T + 1), generator=g)
+                caps[:, 0] = 1
+                for r in range(B):
+                    n = int(torch.randint(3, T, (1,), generator=g))
+                    caps[r, n] = 2
+                    caps[r, n + 1:] = 0
+                caps = caps.cuda()
+        else:
+            feats = torch.rand(B, 1000, generator=g).cuda()
+        if step == 4:
+            ta.scheduler_step(4)    # epoch 4 done: StepLR(5, 0.8) lowers the rate, on the host and in device memory
+            tb.scheduler_step(4)
+        la.append(float(ta.step(feats, caps).item()))
+        lb.append(float(tb.step(feats, caps).item()))
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-5 * abs(x), (la, lb)
+    assert abs(lb[1] - lb[2]) > 1e-6 * abs(lb[1])           # two replays on the same batch: different masks, and
+    assert tb.t == 6 and tb.state.read()[1] == 6             # different weights
+    assert abs(tb.lr - 8e-4) < 1e-12 and abs(tb.state.read()[2] - 8e-4) < 1e-9
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        if va.is_floating_point():
+            assert float((va - vb).abs().max()) <= 2.2 * 1e-3 * 6 * 1e-2 + 1e-6, k
+    assert int(b.state_dict()["batchnorm.num_batches_tracked"]) == 6
+
+
+def test_scheduler_step_is_steplr_5_08():
+    """StepLR(step_size=5, gamma=0.8) stepped once per epoch (reference train.py:218,366), against torch's own."""
+    from capdec.trainer import CaptionTrainer
+    from models.cnnattn_model import CNNAttentionModel
+    m = CNNAttentionModel(32, 40, 4, 1).cuda()
+    tr = CaptionTrainer(m, lr=1e-3)
+    w = torch.zeros(1, requires_grad=True)
+    opt = torch.optim.Adam([w], lr=1e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=5, gamma=0.8)
+    for epoch in range(23):
+        opt.step()
+        sched.step()
+        got = tr.scheduler_step(epoch)
+        assert abs(got - sched.get_last_lr()[0]) <= 1e-12, epoch
+    assert abs(tr.state.read()[2] - sched.get_last_lr()[0]) <= 1e-9
+
+
 def test_adam_step_matches_torch_formula():
     from capdec import ops
     g = torch.Generator().manual_seed(0)
@@ -390,9 +489,11 @@ def test_adam_step_matches_torch_formula():
     close(p, ref.detach(), rtol=1e-6)
 
 
-def test_trainer_steps_match_oracle_training_loop():
+@pytest.mark.parametrize("graph", [False, True])
+def test_trainer_steps_match_oracle_training_loop(graph):
     """CaptionTrainer (flat buffers, fused loss, HIP Adam) against the oracle forward + torch autograd + torch.optim.Adam
-    on the CPU, 4 steps of the reference's inner loop (train.py:252-262), dropout off."""
+    on the CPU, 4 steps of the reference's inner loop (train.py:252-262), dropout off; launch by launch and with the
+    step captured in a HIP graph (first step launched, second captured and replayed, third and fourth replayed)."""
     from capdec.trainer import CaptionTrainer
     from models.vitcnnattn_model import VITCNNAttentionModel
     from oracle import decoder_ref as R
@@ -424,7 +525,7 @@ def test_trainer_steps_match_oracle_training_loop():
         ref_losses.append(float(loss.detach()))
     # HIP trainer
     m = m.cuda()
-    tr = CaptionTrainer(m, lr=1e-3)
+    tr = CaptionTrainer(m, lr=1e-3, graph=graph)
     losses = [tr.step(feats.cuda(), caps.cuda()) for _ in range(4)]
     losses = [float(l.item()) for l in losses]
     for a, b in zip(losses, ref_losses):
@@ -474,9 +575,10 @@ def test_f7_cnn_rnn_train_logits_loss_and_all_gradients():
     assert n == len(list(m.parameters()))
 
 
-def test_cnn_rnn_trainer_matches_oracle_training_loop():
+@pytest.mark.parametrize("graph", [False, True])
+def test_cnn_rnn_trainer_matches_oracle_training_loop(graph):
     """CaptionTrainer on CNNtoRNN (fused loss on time-major rows, flat buffers, HIP Adam) against the oracle forward +
-    torch autograd + torch.optim.Adam on the CPU."""
+    torch autograd + torch.optim.Adam on the CPU; launch by launch and captured in a HIP graph."""
     from capdec.trainer import CaptionTrainer
     from oracle import decoder_ref as R
     fx = load_golden("f7_decoder_rnn")
@@ -495,7 +597,7 @@ def test_cnn_rnn_trainer_matches_oracle_training_loop():
         for k, v in new.items():
             sd[k] = v
         ref_losses.append(float(loss.detach()))
-    tr = CaptionTrainer(m, lr=1e-3)
+    tr = CaptionTrainer(m, lr=1e-3, graph=graph)
     losses = [float(tr.step(feats.cuda(), caps.cuda()).item()) for _ in range(3)]
     for a, b in zip(losses, ref_losses):
         assert abs(a - b) <= 1e-4 * abs(b), (losses, ref_losses)
