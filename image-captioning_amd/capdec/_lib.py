@@ -9,12 +9,14 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcapdec.so")
+LIB_TUNE_PATH = os.path.join(HERE, "libcapdec_tune.so")
 
 ABI_VERSION = 2
 GEMM_RELU = 1
 GEMM_TP = 2
 GEMM_TQ = 4
 GEMM_ATOMIC = 8
+GEMM_SPLITK = 16
 DECODE_NO_S1_SHORTCUT = 1
 VOCAB_STATIC_MAX_ELEMS = 1 << 20
 E2BIG = -7
@@ -29,7 +31,8 @@ class GemmGroup(Structure):
 
 class GemmExtra(Structure):
     _fields_ = [("mask", c_void_p), ("ldm", c_int64), ("lse", c_void_p), ("tgt", c_void_p), ("gscale", c_void_p),
-                ("ignore_index", c_int64), ("rows_dev", c_void_p), ("k_dev", c_void_p)]
+                ("ignore_index", c_int64), ("rows_dev", c_void_p), ("k_dev", c_void_p), ("splitk_ws", c_void_p),
+                ("splitk_ws_elems", c_int64)]
 
 
 class AttnW(Structure):
@@ -66,6 +69,7 @@ _SIGNATURES = {
     "capdec_abi_version": (c_int, []),
     "capdec_strerror": (c_char_p, [c_int]),
     "capdec_gemm": (c_int, [POINTER(GemmGroup), c_int, c_int, c_int, _P]),
+    "capdec_gemm_splitk_workspace_elems": (c_size_t, [c_int, c_int, c_int]),
     "capdec_vocab_tiles": (c_int, [c_int]),
     "capdec_vocab_partial_elems": (c_size_t, [c_int, c_int]),
     "capdec_vocab_argmax_partial": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
@@ -78,9 +82,6 @@ _SIGNATURES = {
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P]),
     "capdec_lstm_step": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P, _P]),
     "capdec_lstm_step_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, _P, _P, _P]),
-    "capdec_gemm_force_config": (c_int, [c_int]),
-    "capdec_gemm_force_staging": (c_int, [c_int]),
-    "capdec_lstm_force_staging": (c_int, [c_int]),
     "capdec_gemm_ex": (c_int, [POINTER(GemmGroup), c_int, c_int, c_int, POINTER(GemmExtra), _P]),
     "capdec_dropout": (c_int, [_P, c_int64, c_float, c_uint64, _P, _P, _P]),
     "capdec_add_layernorm_train": (c_int, [_P, c_int, _P, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
@@ -93,7 +94,6 @@ _SIGNATURES = {
     "capdec_group_sum": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "capdec_embed_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "capdec_bn_train_backward": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
-    "capdec_attention_bwd_force_two_pass": (c_int, [c_int]),
     "capdec_attention_bwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P,
                                      _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
@@ -112,7 +112,6 @@ _SIGNATURES = {
     "capdec_cross_attention_bwd_ragged": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P,
                                                   c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, c_int,
                                                   _P, _P]),
-    "capdec_attention_force_row_kernel": (c_int, [c_int]),
     "capdec_attention_bwd_ragged": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64,
                                             _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "capdec_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
@@ -151,37 +150,80 @@ _SIGNATURES = {
     "capdec_vocab_argmax_static": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
 }
 
-_lib = None
+# include/capdec_tuning.h: exported by the tuning build only
+_TUNING_SIGNATURES = {
+    "capdec_gemm_force_config": (c_int, [c_int]),
+    "capdec_gemm_force_staging": (c_int, [c_int]),
+    "capdec_lstm_force_staging": (c_int, [c_int]),
+    "capdec_attention_bwd_force_two_pass": (c_int, [c_int]),
+    "capdec_attention_force_row_kernel": (c_int, [c_int]),
+}
+
+_lib = None          # the library every wrapper of this package calls
+_product = None
+_tuning = None
 
 
-def load():
-    """Load libcapdec.so once; raise loudly if it is missing or has the wrong ABI."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path, signatures):
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"libcapdec.so not found at {LIB_PATH}: the HIP kernels are the only implementation of this package "
+            f"{os.path.basename(path)} not found at {path}: the HIP kernels are the only implementation of this package "
             "(no CPU fallback). Build them with `python image-captioning_amd/capdec/_build.py` (needs hipcc).")
-    # PyTorch ships its own HIP runtime; it must be the one already mapped when libcapdec.so resolves its HIP symbols,
+    # PyTorch ships its own HIP runtime; it must be the one already mapped when the library resolves its HIP symbols,
     # or the process ends up with two runtimes and this library's copy finds no device.
     import torch  # noqa: F401
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGNATURES.items():
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in signatures.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise RuntimeError(f"libcapdec.so does not export {name}; rebuild it") from e
+            raise RuntimeError(f"{os.path.basename(path)} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
     if lib.capdec_abi_version() != ABI_VERSION:
-        raise RuntimeError("libcapdec.so ABI version mismatch; rebuild it")
-    _lib = lib
+        raise RuntimeError(f"{os.path.basename(path)} ABI version mismatch; rebuild it")
     return lib
+
+
+def load():
+    """The library in use: libcapdec.so, loaded once (or the tuning build inside ``tuning_build()``); raises loudly if
+    it is missing or has the wrong ABI."""
+    global _lib, _product
+    if _lib is not None:
+        return _lib
+    _product = _open(LIB_PATH, _SIGNATURES)
+    _lib = _product
+    return _lib
+
+
+class tuning_build:
+    """Context manager for tests and benchmark tools: inside it every wrapper of this package calls libcapdec_tune.so,
+    the same kernels compiled with the process-wide kernel-selection overrides of include/capdec_tuning.h; yields that
+    library.  The overrides are reset on exit and the product library is put back."""
+
+    def __enter__(self):
+        global _lib, _tuning
+        load()
+        if _tuning is None:
+            _tuning = _open(LIB_TUNE_PATH, {**_SIGNATURES, **_TUNING_SIGNATURES})
+        self._saved = _lib
+        _lib = _tuning
+        return _tuning
+
+    def __exit__(self, *exc):
+        global _lib
+        for name in _TUNING_SIGNATURES:
+            getattr(_tuning, name)(0)
+        _lib = self._saved
+        return False
 
 
 def exported_symbols():
     return sorted(_SIGNATURES)
+
+
+def tuning_symbols():
+    return sorted(_TUNING_SIGNATURES)
 
 
 def check(rc, what):

@@ -373,8 +373,7 @@ def head_forward(model, parts, x, dropout_first, seed, seed_dev=None):
     t.xin = xin
     B = x.shape[0]
     E = parts[0][0].weight.shape[0]
-    split = any(hi - lo >= 8192 for _, lo, hi in parts)
-    z = (torch.zeros if split else torch.empty)((B, len(parts) * E), device=x.device, dtype=torch.float32)
+    z = torch.empty((B, len(parts) * E), device=x.device, dtype=torch.float32)
     for n, (fc, lo, hi) in enumerate(parts):
         ops.linear(xin[:, lo:hi], fc.weight, fc.bias, out=z[:, n * E:(n + 1) * E], split_k=(hi - lo >= 8192))
     if not dropout_first and p > 0:

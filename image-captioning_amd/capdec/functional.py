@@ -28,9 +28,9 @@ def linear_dropout_bn(model, parts, x, dropout_first=False):
         return AG.head_train(model, parts, x, dropout_first)
     B = x.shape[0]
     E = parts[0][0].weight.shape[0]
-    # a long contraction with few output tiles (the 86436-wide YOLO projection) is split over workgroups
-    split = any(hi - lo >= 8192 for _, lo, hi in parts)
-    out = (torch.zeros if split else torch.empty)((B, len(parts) * E), device=x.device, dtype=torch.float32)
+    # a long contraction with few output tiles (the 86436-wide YOLO projection) is split over workgroups, its partial
+    # sums added in a fixed order: the memory rows, and with them the decoded tokens, repeat exactly from run to run
+    out = torch.empty((B, len(parts) * E), device=x.device, dtype=torch.float32)
     scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
     for n, (fc, lo, hi) in enumerate(parts):
         ops.linear(x[:, lo:hi], fc.weight, fc.bias, scale=scale[n * E:(n + 1) * E], shift=shift[n * E:(n + 1) * E],

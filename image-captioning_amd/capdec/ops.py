@@ -42,9 +42,10 @@ def _row_stride(t, name):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
-def gemm_groups(groups, K, relu=False, extra_flags=0, rows_dev=None):
+def gemm_groups(groups, K, relu=False, extra_flags=0, rows_dev=None, split_k=False):
     """groups: list of dicts with P,Q,C (2-D, row-contiguous) and optional bias_j,bias_i,scale_j,shift_j,R.
-    rows_dev: int32 device scalar; only the first rows_dev[0] output rows are computed."""
+    rows_dev: int32 device scalar; only the first rows_dev[0] output rows are computed.
+    split_k (one group): long contraction split over workgroups with the partial sums added in a fixed order."""
     lib = _lib.load()
     n = len(groups)
     arr = (GemmGroup * n)()
@@ -72,6 +73,15 @@ def gemm_groups(groups, K, relu=False, extra_flags=0, rows_dev=None):
                 raise RuntimeError("capdec gemm: residual shape mismatch")
             g.R, g.ldri, g.ldrj = R.data_ptr(), _row_stride(R, "R"), 1
     flags = (_lib.GEMM_RELU if relu else 0) | extra_flags
+    if split_k:
+        if n != 1 or rows_dev is not None:
+            raise RuntimeError("capdec gemm: split_k takes one group and no row limit")
+        elems = lib.capdec_gemm_splitk_workspace_elems(arr[0].I, arr[0].J, K)
+        ws = torch.empty(max(int(elems), 1), device=groups[0]["C"].device, dtype=torch.float32)
+        ex = _lib.GemmExtra()
+        ex.splitk_ws, ex.splitk_ws_elems = ws.data_ptr(), ws.numel()
+        _lib.check(lib.capdec_gemm_ex(arr, n, K, flags | _lib.GEMM_SPLITK, byref(ex), _stream()), "capdec_gemm_ex")
+        return
     if rows_dev is None:
         _lib.check(lib.capdec_gemm(arr, n, K, flags, _stream()), "capdec_gemm")
         return
@@ -82,16 +92,16 @@ def gemm_groups(groups, K, relu=False, extra_flags=0, rows_dev=None):
 
 def linear(x, W, b=None, relu=False, residual=None, scale=None, shift=None, out=None, split_k=False, rows_dev=None):
     """y = x W^T + b with fused epilogue; x [M,K] (row stride free), W [N,K].
-    split_k: split the contraction over workgroups and add the partial sums with float atomics (long K, few
-    output tiles: the 86436-wide YOLO head).  ``out`` must then hold zeros; no relu / residual."""
+    split_k: split the contraction over workgroups (long K, few output tiles: the 86436-wide YOLO head); the partial
+    sums go to a scratch tensor and are added in a fixed order, so the result is the same from run to run."""
     _chk(x, name="x")
     _chk(W, name="W")
     M, K = x.shape
     N = W.shape[0]
     if out is None:
-        out = (torch.zeros if split_k else torch.empty)((M, N), device=x.device, dtype=torch.float32)
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
     gemm_groups([dict(P=x, Q=W, C=out, bias_j=b, R=residual, scale_j=scale, shift_j=shift)], K, relu,
-                extra_flags=_lib.GEMM_ATOMIC if split_k else 0, rows_dev=rows_dev)
+                rows_dev=rows_dev, split_k=split_k)
     return out
 
 

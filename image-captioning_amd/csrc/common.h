@@ -24,6 +24,16 @@
         if (rc__ != 0) return rc__; \
     } while (0)
 
+// Kernel-selection overrides exist only in the tuning build of the library (libcapdec_tune.so, compiled with
+// -DCAPDEC_TUNING_HOOKS for the tests and benchmarks that compare kernel variants; see include/capdec_tuning.h).  In
+// the product build they are compile-time zeros, so the library holds no mutable state that a call could depend on.
+#ifdef CAPDEC_TUNING_HOOKS
+#include "../../include/capdec_tuning.h"
+#define CAPDEC_HOOK_VAR(name) int name = 0
+#else
+#define CAPDEC_HOOK_VAR(name) constexpr int name = 0
+#endif
+
 static inline bool capdec_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Per-tile partial results of the fused vocabulary projections: blocks of 64 rows, [row block][vocabulary tile][64],

@@ -560,6 +560,11 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
                     // c_rows: output row i is stored at row c_rows[i] (k/v of a decode step go straight to their cache rows)
                     const int64_t ci = g.c_rows ? (int64_t)(RPRE ? cpre[RPRE ? e : 0] : g.c_rows[i]) : (int64_t)i;
                     float* c = &g.C[ci * g.ldci + (int64_t)j * g.ldcj];
+                    if (atomic && x.splitk_ws) {
+                        // fixed-order split-K: the raw partial sum of this k-range goes to its own slab
+                        x.splitk_ws[((int64_t)split * g.I + i) * g.J + j] = acc[ti][tj][e];
+                        continue;
+                    }
                     if (atomic) {
                         // C += partial; the affine terms (bias, BatchNorm shift) enter once, with the first k-range
                         float v = acc[ti][tj][e];
@@ -595,7 +600,10 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
                     const int64_t ci = g.c_rows ? (int64_t)g.c_rows[i] : (int64_t)i;
                     off[e] = ci * g.ldci + (int64_t)j * g.ldcj;
                     float v;
-                    if (atomic) {
+                    if (atomic && x.splitk_ws) {
+                        off[e] = ((int64_t)split * g.I + i) * g.J + j;
+                        v = acc[ti][tj][e];
+                    } else if (atomic) {
                         v = acc[ti][tj][e];
                         if (split == 0) {
                             v += bj;
@@ -621,11 +629,30 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     if (off[e] < 0) continue;
-                    if (atomic) atomicAdd(&g.C[off[e]], val[e]);
+                    if (atomic && x.splitk_ws) x.splitk_ws[off[e]] = val[e];
+                    else if (atomic) atomicAdd(&g.C[off[e]], val[e]);
                     else g.C[off[e]] = val[e];
                 }
             }
         }
+    }
+}
+
+// Second stage of the fixed-order split-K: C[i,j] = epi(ws[0][i][j] + ws[1][i][j] + ... ) with the slabs added in
+// index order by one thread per element, so the sum does not depend on which workgroup finished first.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, capdec_gemm_group g,
+                                                            int relu) {
+    const int64_t n = (int64_t)g.I * g.J;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / g.J), j = (int)(idx - (int64_t)i * g.J);
+        float v = ws[idx];
+        for (int sp = 1; sp < nsplit; ++sp) v += ws[(int64_t)sp * n + idx];
+        if (g.bias_j) v += g.bias_j[j];
+        if (g.bias_i) v += g.bias_i[i];
+        if (g.scale_j) v = v * g.scale_j[j] + g.shift_j[j];
+        if (relu) v = fmaxf(v, 0.f);
+        if (g.R) v += g.R[(int64_t)i * g.ldri + (int64_t)j * g.ldrj];
+        g.C[(int64_t)i * g.ldci + (int64_t)j * g.ldcj] = v;
     }
 }
 
@@ -799,7 +826,7 @@ __global__ __launch_bounds__(256) void nll_finalize_kernel(const float* __restri
 }
 
 // 0: automatic; 1: operand tiles always staged through registers
-int g_staging = 0;
+CAPDEC_HOOK_VAR(g_staging);
 
 // workgroups above 64 KiB of dynamic LDS need the limit raised once per kernel
 template <typename F>
@@ -809,19 +836,31 @@ bool allow_lds(F* kernel, size_t bytes) {
                                (int)bytes) == hipSuccess;
 }
 
+// split the contraction until about four workgroups per CU exist, at least 4 k-tiles per split, at most 64 splits
+inline int splitk_count(long tiles, int nk) {
+    long want = (1024 + tiles - 1) / tiles;
+    const long cap = nk / 4 > 0 ? nk / 4 : 1;
+    int n = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    return n > 64 ? 64 : n;
+}
+// tile form and split count of a split contraction of one I x J x K problem (the rule of launch_gemm_layout)
+inline int splitk_plan(int I, int J, int K) {
+    const long tiles64 = (long)((I + 63) / 64) * ((J + 63) / 64);
+    if (tiles64 >= 1024) return splitk_count((long)((I + 127) / 128) * ((J + 127) / 128), (K + 15) / 16);
+    return splitk_count(tiles64, (K + 31) / 32);
+}
+
 template <int WM, int WI, int WJ, int BK, bool TP, bool TQ, int KG>
 int launch_gemm_cfg(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hipStream_t s) {
     constexpr int BI = 32 * WM * WI, BJ = 64 * WJ, NT = 128 * WM * KG;
     const int ti = (maxI + BI - 1) / BI, tj = (maxJ + BJ - 1) / BJ;
     const int nk = (a.K + BK - 1) / BK;
     a.nsplit = 1;
-    if (a.flags & CAPDEC_GEMM_ATOMIC) {
-        // split the contraction until about four workgroups per CU exist, at least 4 k-tiles per split
-        const long tiles = (long)ti * tj * ngroups;
-        long want = (1024 + tiles - 1) / tiles;
-        const long cap = nk / 4 > 0 ? nk / 4 : 1;
-        a.nsplit = (int)(want < 1 ? 1 : (want > cap ? cap : want));
-        if (a.nsplit > 64) a.nsplit = 64;
+    if (a.flags & CAPDEC_GEMM_ATOMIC) a.nsplit = splitk_count((long)ti * tj * ngroups, nk);
+    if (a.x.splitk_ws) {
+        // fixed-order split-K: one slab of partial sums per k-range, no more of them than the workspace holds
+        const long fit = (long)(a.x.splitk_ws_elems / ((int64_t)maxI * maxJ));
+        if (a.nsplit > fit) a.nsplit = fit < 1 ? 1 : (int)fit;
     }
     dim3 grid(make_tile_map(a.map, ti, tj, ngroups * a.nsplit, a.nsplit >= 8), 1, 1);
     constexpr size_t smem = lds_floats<WM, WI, WJ, BK, TP, TQ, KG>() * sizeof(float);
@@ -845,7 +884,7 @@ int launch_gemm_cfg(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hip
 
 // Tile choice.  cfg = 0: automatic; otherwise force: 11 / 116 = 64x64 (BK 32 / 16), 22 / 216 = 128x128 (BK 32 / 16),
 // 32 / 316 = 32x64 tile with the k-loop split over the workgroup's two wave pairs (BK 32 / 16).
-int g_force_cfg = 0;
+CAPDEC_HOOK_VAR(g_force_cfg);
 
 template <bool TP, bool TQ>
 int launch_gemm_layout(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hipStream_t s) {
@@ -906,6 +945,27 @@ int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int 
     if (!tp || !tq) vec = vec && (K % 4 == 0) && K >= 4;   // a k-contiguous operand is read four k at a time
     for (int n = ngroups; n < 4; ++n) a.g[n] = a.g[0];
     if (maxI == 0 || maxJ == 0) return 0;
+    if (flags & CAPDEC_GEMM_SPLITK) {
+        // fixed-order split-K: partial sums into the caller's workspace, then one pass that adds them in index order
+        const capdec_gemm_group& g = groups[0];
+        CAPDEC_REQUIRE(ngroups == 1 && !(flags & CAPDEC_GEMM_ATOMIC) && !g.c_rows && !a.x.mask && !a.x.lse && !a.x.rows_dev &&
+                       !a.x.k_dev && a.x.splitk_ws);
+        if ((size_t)a.x.splitk_ws_elems < (size_t)g.I * g.J) return CAPDEC_ENOMEM;      // room for one slab at least
+        a.flags = (flags & ~(CAPDEC_GEMM_SPLITK | CAPDEC_GEMM_RELU)) | CAPDEC_GEMM_ATOMIC;
+        int rc;
+        if (tp) rc = launch_gemm_layout<true, true>(a, 1, maxI, maxJ, vec, s);
+        else if (tq) rc = launch_gemm_layout<false, true>(a, 1, maxI, maxJ, vec, s);
+        else rc = launch_gemm_layout<false, false>(a, 1, maxI, maxJ, vec, s);
+        if (rc != 0) return rc;
+        const int nsplit = a.nsplit;                       // as many k-ranges as the launcher chose and the workspace holds
+        const int64_t n = (int64_t)g.I * g.J;
+        const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.x.splitk_ws, nsplit, g,
+                           (flags & CAPDEC_GEMM_RELU) ? 1 : 0);
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
+    a.x.splitk_ws = nullptr;
     if ((flags & CAPDEC_GEMM_ATOMIC) && ((flags & CAPDEC_GEMM_RELU) || a.x.mask || a.x.lse)) return CAPDEC_EINVAL;
     for (int n = 0; n < ngroups; ++n)
         if ((flags & CAPDEC_GEMM_ATOMIC) && groups[n].R) return CAPDEC_EINVAL;
@@ -916,6 +976,7 @@ int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int 
 
 extern "C" {
 
+#ifdef CAPDEC_TUNING_HOOKS
 int capdec_gemm_force_config(int cfg) {
     CAPDEC_REQUIRE(cfg == 0 || cfg == 11 || cfg == 22 || cfg == 216 || cfg == 32 || cfg == 116 || cfg == 316);
     g_force_cfg = cfg;
@@ -926,6 +987,12 @@ int capdec_gemm_force_staging(int mode) {
     CAPDEC_REQUIRE(mode == 0 || mode == 1);
     g_staging = mode;
     return 0;
+}
+#endif
+
+size_t capdec_gemm_splitk_workspace_elems(int I, int J, int K) {
+    if (I < 1 || J < 1 || K < 1) return 0;
+    return (size_t)splitk_plan(I, J, K) * (size_t)I * (size_t)J;
 }
 
 int capdec_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, void* stream) {

@@ -332,15 +332,17 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs a) {
     a.dc0[idx] = dc * sf;
 }
 
-int g_lstm_staging = 0;   // 0: automatic; 1: always the register-staged kernel (tests compare the two)
+CAPDEC_HOOK_VAR(g_lstm_staging);   // 0: automatic; 1: always the register-staged kernel (tests compare the two)
 
 }  // namespace
 
+#ifdef CAPDEC_TUNING_HOOKS
 extern "C" int capdec_lstm_force_staging(int mode) {
     CAPDEC_REQUIRE(mode == 0 || mode == 1);
     g_lstm_staging = mode;
     return 0;
 }
+#endif
 
 extern "C" int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, const float* w_ih,
                                 const float* w_hh, const float* b_ih, const float* b_hh, int B, int E, int Hd,

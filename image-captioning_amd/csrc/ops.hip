@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void bn_train_kernel(const float* __restrict__
     }
 }
 
-int g_attention_no_long = 0;   // tests: 1 keeps long memories on the one-wavefront-per-row kernel
+CAPDEC_HOOK_VAR(g_attention_no_long);   // tests: 1 keeps long memories on the one-wavefront-per-row kernel
 
 }  // namespace
 
@@ -767,10 +767,12 @@ int capdec_cross_attention_ragged(const float* q, int64_t ldq, const float* k, i
     return 0;
 }
 
+#ifdef CAPDEC_TUNING_HOOKS
 int capdec_attention_force_row_kernel(int on) {
     g_attention_no_long = on ? 1 : 0;
     return 0;
 }
+#endif
 
 int capdec_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                    float eps, int C, float* scale, float* shift, void* stream) {

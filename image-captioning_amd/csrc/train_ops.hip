@@ -1349,11 +1349,13 @@ int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma
     return 0;
 }
 
-static int g_attn_bwd_two_pass = 0;
+static CAPDEC_HOOK_VAR(g_attn_bwd_two_pass);
+#ifdef CAPDEC_TUNING_HOOKS
 int capdec_attention_bwd_force_two_pass(int on) {
     g_attn_bwd_two_pass = on ? 1 : 0;
     return 0;
 }
+#endif
 
 int capdec_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                 const float* dout, int64_t ldo, const float* lse, float* dq, int64_t lddq, float* dk,

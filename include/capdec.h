@@ -12,7 +12,9 @@
  *  - return value: 0 on success, a negative CAPDEC_E* code on bad arguments (nothing was launched),
  *    or a positive hipError_t from the launch;
  *  - no entry point synchronises the host; no global mutable state: calls on different streams
- *    are independent.
+ *    are independent.  (Two exceptions, both documented at their entry points: capdec_vocab_argmax_static owns a
+ *    fixed device array, and the kernel-selection overrides of include/capdec_tuning.h exist only in the separate
+ *    tuning build libcapdec_tune.so, never in this library.)
  */
 #ifndef CAPDEC_H
 #define CAPDEC_H
@@ -66,7 +68,14 @@ typedef struct capdec_gemm_group {
                              /* C must hold the value to add to (zero it for a plain product); only bias   */
                              /* and scale/shift epilogues are allowed; sums differ in the last bits from    */
                              /* run to run (arrival order).                                                 */
+#define CAPDEC_GEMM_SPLITK 16 /* one group, long K, few output tiles (the 86436-wide YOLO projection,          */
+                             /* yolocnnattn_model.py:75, yoloattn_model.py:70): the contraction is split over     */
+                             /* workgroups as with ATOMIC, but every k-range stores its partial sums to its own   */
+                             /* slab of extra->splitk_ws and a second kernel adds the slabs in index order and    */
+                             /* applies the epilogue: the result is the same bit for bit from run to run.         */
+                             /* Needs capdec_gemm_ex with splitk_ws of capdec_gemm_splitk_workspace_elems floats. */
 int capdec_gemm(const capdec_gemm_group* groups /*host*/, int ngroups, int K, int flags, void* stream);
+size_t capdec_gemm_splitk_workspace_elems(int I, int J, int K);
 
 /* Backward forms of nn.Linear y = x W^T + b (autograd of the same reference lines) use the layout flags:
  *   dX[m,k] = sum_n dY[m,n] W[n,k] :  P = dY [M,N], Q = W stored [N(k-axis), K(j-axis)]  -> TQ
@@ -84,14 +93,9 @@ typedef struct capdec_gemm_extra {
     const int32_t* k_dev;      /* nullable device scalar: the contraction runs over k < min(K, k_dev[0]) only; whole
                                   32-deep k-tiles are read, so both operands must hold zeros (or finite values against
                                   zeros) from k_dev[0] up to the next multiple of 32 */
+    float* splitk_ws;          /* CAPDEC_GEMM_SPLITK: device scratch for the partial sums */
+    int64_t splitk_ws_elems;   /* its size in floats */
 } capdec_gemm_extra;
-/* Tuning hook for benchmarks: 0 = automatic tile choice, 11 / 116 = 64x64 (BK 32 / 16), 22 / 216 = 128x128 (BK 32 / 16),
- * 32 / 316 = 32x64 tile with its k-loop split over the two wave pairs (BK 32 / 16).  Process-wide; not for production
- * use. */
-int capdec_gemm_force_config(int cfg);
-/* Tuning hook for benchmarks: 0 = automatic, 1 = operand tiles always staged through registers (never loaded straight
- * into LDS).  Process-wide; not for production use. */
-int capdec_gemm_force_staging(int mode);
 int capdec_gemm_ex(const capdec_gemm_group* groups /*host*/, int ngroups, int K, int flags,
                    const capdec_gemm_extra* extra /*host, nullable*/, void* stream);
 
@@ -260,12 +264,6 @@ int capdec_cross_attention_bwd_ragged(const float* q, int64_t ldq, const float* 
                                       const float* lse, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
                                       int64_t lddv, int B, int H, int T, int S, int dkh, const int32_t* seq_off,
                                       void* stream);
-/* Test hook: sequences up to 64 positions normally take a one-pass kernel that keeps a (b,h) slice in LDS; on != 0
- * forces the general two-pass kernels (any length up to 2048).  Process-wide; not for production use. */
-int capdec_attention_bwd_force_two_pass(int on);
-/* Tuning hook for tests: non-zero keeps long unmasked memories (Tk > 64) on the one-wavefront-per-row forward kernel
- * instead of the chunked one.  Process-wide; not for production use. */
-int capdec_attention_force_row_kernel(int on);
 /* Materialised form of the same loss (train.py:216,254-256) for training, where the backward pass needs the
  * softmax anyway: logits [M,V] (row stride ld) are overwritten in place with d(mean NLL)/d(logits) =
  * (softmax - onehot(target)) / n_counted (zero rows for ignored targets).  sums must be zeroed by the caller:
@@ -327,9 +325,6 @@ int capdec_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n
 int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, const float* w_ih,
                      const float* w_hh, const float* b_ih, const float* b_hh, int B, int E, int Hd, float* h1,
                      int64_t ldh1, float* c1, float* gates_out, void* stream);
-/* Tuning hook for tests and benchmarks: 0 = automatic, 1 = always the register-staged kernel (shapes with E and Hd
- * multiples of 32 otherwise take the kernel whose loads write LDS directly).  Process-wide; not for production use. */
-int capdec_lstm_force_staging(int mode);
 
 /* Backward of one capdec_lstm_step (autograd of nn.LSTM inside DecoderRNN.forward, cnnrnn_model.py:29-30):
  * gates [B,4Hd] = the pre-activations saved by the forward step, c0 (NULL = zero) / c1 the cell state before /

@@ -1,0 +1,34 @@
+/*
+ * capdec_tuning.h -- kernel-selection overrides of the TUNING build of the library (libcapdec_tune.so).
+ *
+ * The product library libcapdec.so is compiled without them: there the choices below are compile-time constants and
+ * the library keeps no state between calls.  The tuning build is the same sources compiled with
+ * -DCAPDEC_TUNING_HOOKS; it exports everything capdec.h declares plus these five process-wide switches, which the
+ * tests use to run one input through two kernel variants (and compare them bit for bit) and the benchmark tools use to
+ * time tile shapes.  They have no counterpart in the reference.  Not thread-safe; never link this build into a server.
+ */
+#ifndef CAPDEC_TUNING_H
+#define CAPDEC_TUNING_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* contraction tiles: 0 = automatic, 11 / 116 = 64x64 (BK 32 / 16), 22 / 216 = 128x128 (BK 32 / 16), 32 / 316 = 32x64 tile
+ * with its k-loop split over the two wave pairs (BK 32 / 16) */
+int capdec_gemm_force_config(int cfg);
+/* 0 = automatic, 1 = operand tiles always staged through registers (never loaded straight into LDS) */
+int capdec_gemm_force_staging(int mode);
+/* the same choice for the LSTM step kernel */
+int capdec_lstm_force_staging(int mode);
+/* non-zero: attention backward always takes the general two-pass kernels (sequences up to 64 positions normally take a
+ * one-pass kernel that keeps a (batch, head) slice in LDS) */
+int capdec_attention_bwd_force_two_pass(int on);
+/* non-zero: long unmasked memories (more than 64 keys) stay on the one-wavefront-per-row forward kernel instead of the
+ * chunked one */
+int capdec_attention_force_row_kernel(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPDEC_TUNING_H */

@@ -49,3 +49,12 @@ class Vocab:
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture
+def tuning_lib():
+    """libcapdec_tune.so (the kernels compiled with the kernel-selection overrides of include/capdec_tuning.h) as the
+    library every ``capdec.ops`` wrapper calls for the duration of one test; the overrides are reset afterwards."""
+    from capdec import _lib
+    with _lib.tuning_build() as lib:
+        yield lib

@@ -155,6 +155,64 @@ def test_cfg5_yolocnn_attn_greedy_shard():
     check_greedy([got[r] for r in rows], sd, want_enc, H, 20)
     sub = _rows(*m.caption_ids(fd[512:544], max_length=20))
     assert sum(a != b for a, b in zip(sub, got[512:544])) <= 1
+    # The split contraction adds its partial sums in a fixed order: the same input gives the same memory rows bit for
+    # bit and, with them, the same tokens on every run (float atomics would differ in the last bits from run to run,
+    # enough to flip a token at a near-tie).
+    with torch.no_grad():
+        enc2 = m.encode_features(fd)
+    assert torch.equal(enc, enc2)
+    ids_a, len_a = m.caption_ids(fd, max_length=20)
+    ids_b, len_b = m.caption_ids(fd, max_length=20)
+    assert torch.equal(ids_a, ids_b) and torch.equal(len_a, len_b)
+
+
+def test_yolo_attn_single_head_logits_and_greedy():
+    """YOLOAttentionModel (yoloattn_model.py:63-93): one 86436-wide projection -> BatchNorm -> one memory row; logits
+    and greedy ids against the oracle composed of head_single + decoder_forward, eval and training mode."""
+    from models.yoloattn_model import YOLOAttentionModel
+    torch.manual_seed(3)
+    Ey, Vy = 128, 300
+    m = YOLOAttentionModel(Ey, Vy, 4, 1, dropout=0.0).eval()
+    with torch.no_grad():
+        m.batchnorm.running_mean.normal_(0, 0.1)
+        m.batchnorm.running_var.uniform_(0.5, 1.5)
+    sd = cpu_sd(m)
+    g = torch.Generator().manual_seed(1234 + 6)
+    B, T = 24, 12
+    feats = torch.rand(B, 86436, generator=g)
+    caps = _captions(g, B, T, Vy)
+    want_enc, _ = R.head_single(sd, feats, "fc_yolo", training=False)
+    want_logits = R.decoder_forward(sd, want_enc, caps[:, :-1], 4)
+    m = m.cuda()
+    with torch.no_grad():
+        enc = m.encode_features(feats.cuda())
+        logits = m(feats.cuda(), caps[:, :-1].cuda(), "precomputed")
+    close(enc, want_enc, what="memory row")
+    close(logits, want_logits, what="eval logits")
+    got = _rows(*m.caption_ids(feats.cuda(), max_length=12))
+    check_greedy(got, sd, want_enc, 4, 12)
+    vocab_text = m.caption_images(feats[:3].cuda(), type("V", (), {"stoi": {"<SOS>": 1, "<EOS>": 2},
+                                                                  "itos": {i: f"w{i}" for i in range(Vy)}})(),
+                                  "precomputed", max_length=12)
+    assert vocab_text == [" ".join(f"w{i}" for i in row) for row in got[:3]]
+    # training mode: batch statistics, loss and gradients through the split contraction
+    m.train()
+    sd_t = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and k != "positional_encoding.pe")
+            for k, v in sd.items()}
+    enc_t, _ = R.head_single(sd_t, feats, "fc_yolo", training=True)
+    loss_ref = R.caption_loss(R.decoder_forward(sd_t, enc_t, caps[:, :-1], 4), caps[:, 1:])
+    loss_ref.backward()
+    logits_t = m(feats.cuda(), caps[:, :-1].cuda(), "precomputed")
+    loss = torch.nn.functional.cross_entropy(logits_t.reshape(-1, Vy), caps[:, 1:].reshape(-1).cuda(), ignore_index=0)
+    close(loss, loss_ref.detach(), rtol=1e-5, what="training loss")
+    loss.backward()
+    gmax = max(float(v.grad.abs().max()) for v in sd_t.values() if v.requires_grad and v.grad is not None)
+    for k, prm in m.named_parameters():
+        want = sd_t[k].grad
+        if k in ("fc_yolo.bias",) or k.endswith("W_k.bias"):      # mathematically zero: rounding noise on both sides
+            assert float(prm.grad.abs().max()) <= 1e-5 * gmax, k
+            continue
+        close(prm.grad, want, what=f"grad {k}")
 
 
 def test_decode_batch_8192_is_batch_size_independent():

@@ -203,11 +203,11 @@ def test_f9_lstm_step(ops):
 
 
 @pytest.mark.parametrize("B,E,Hd", [(100, 256, 512), (33, 64, 96), (1024, 1024, 512)])
-def test_lstm_step_tiles_loaded_straight_into_lds(ops, B, E, Hd):
+def test_lstm_step_tiles_loaded_straight_into_lds(ops, B, E, Hd, tuning_lib):
     """E and Hd multiples of 32 take the kernel whose loads write LDS directly: against the fp64 cell equations
     (cnnrnn_model.py:17,29-30: nn.LSTM, gates i,f,g,o) and bit for bit against the register-staged kernel."""
     from capdec import _lib
-    lib = _lib.load()
+    lib = tuning_lib
     g = torch.Generator().manual_seed(B + E)
     x, h0, c0 = (torch.randn(B, n, generator=g) for n in (E, Hd, Hd))
     w_ih, w_hh = torch.randn(4 * Hd, E, generator=g) * E ** -0.5, torch.randn(4 * Hd, Hd, generator=g) * Hd ** -0.5
@@ -423,10 +423,11 @@ def test_full_size_decode_cfg2(S):
     assert sum(a != b for a, b in zip(sub, got[256:320])) <= 1   # batch-size independent up to a near-tie
 
 
-def test_gemm_split_k_atomic_and_forced_tiles(ops):
-    """Long contraction split over workgroups (float atomics) and every tile configuration of the kernel."""
+def test_gemm_split_k_atomic_and_forced_tiles(ops, tuning_lib):
+    """Long contraction split over workgroups (partial sums to a scratch tensor, added in a fixed order; float atomics
+    for the weight gradients) and every tile configuration of the kernel."""
     from capdec import _lib
-    lib = _lib.load()
+    lib = tuning_lib
     g = torch.Generator().manual_seed(77)
     x = torch.randn(96, 9000, generator=g)
     W = torch.randn(80, 9000, generator=g)
@@ -437,6 +438,10 @@ def test_gemm_split_k_atomic_and_forced_tiles(ops):
             lib.capdec_gemm_force_config(cfg)
             y = ops.linear(x.cuda(), W.cuda(), b.cuda(), scale=sc.cuda(), shift=sh.cuda(), split_k=True)
             close(y, ref, what=f"split-k cfg {cfg}")
+            # partial sums are added in a fixed order: bit-identical from run to run
+            assert torch.equal(y, ops.linear(x.cuda(), W.cuda(), b.cuda(), scale=sc.cuda(), shift=sh.cuda(), split_k=True))
+            yr = ops.linear(x.cuda(), W.cuda(), b.cuda(), relu=True, residual=y, split_k=True)
+            close(yr, torch.relu(x.double() @ W.double().t() + b.double()) + y.double().cpu(), what=f"split-k relu+residual cfg {cfg}")
             y2 = ops.linear(x.cuda(), W.cuda(), b.cuda(), relu=True)
             close(y2, torch.relu(x.double() @ W.double().t() + b.double()), what=f"plain cfg {cfg}")
             dy = torch.randn(300, 70, generator=g)
@@ -448,11 +453,11 @@ def test_gemm_split_k_atomic_and_forced_tiles(ops):
         lib.capdec_gemm_force_config(0)
 
 
-def test_gemm_tiles_loaded_straight_into_lds(ops):
+def test_gemm_tiles_loaded_straight_into_lds(ops, tuning_lib):
     """Shapes made of whole, aligned k-tiles take the path whose loads write LDS directly: every tile configuration and
     operand layout against fp64, and bit for bit against the register-staged path (same order of sums)."""
     from capdec import _lib
-    lib = _lib.load()
+    lib = tuning_lib
     g = torch.Generator().manual_seed(78)
     x, W, b = torch.randn(200, 1056, generator=g), torch.randn(136, 1056, generator=g), torch.randn(136, generator=g)
     dy, xx = torch.randn(352, 72, generator=g), torch.randn(352, 132, generator=g)
@@ -478,11 +483,11 @@ def test_gemm_tiles_loaded_straight_into_lds(ops):
         lib.capdec_gemm_force_staging(0)
 
 
-def test_gemm_direct_to_lds_edge_shapes_and_device_limits(ops):
+def test_gemm_direct_to_lds_edge_shapes_and_device_limits(ops, tuning_lib):
     """Smallest whole-k-tile shapes, one-row / four-column outputs, and the device-side row and contraction limits
     (0, inside a tile, across tiles) of the contraction kernels."""
     from capdec import _lib
-    lib = _lib.load()
+    lib = tuning_lib
     g = torch.Generator().manual_seed(79)
     try:
         for cfg in (0, 11, 116, 32, 316, 216):
@@ -509,11 +514,11 @@ def test_gemm_direct_to_lds_edge_shapes_and_device_limits(ops):
         lib.capdec_gemm_force_config(0)
 
 
-def test_gemm_epilogue_residual_accumulate_and_mask_in_every_tile(ops):
+def test_gemm_epilogue_residual_accumulate_and_mask_in_every_tile(ops, tuning_lib):
     """Epilogue operands that some tile configurations fetch before the contraction and others in a pass of their own:
     residual, in-place accumulation (R == C), ReLU mask, with and without a device-side row limit."""
     from capdec import _lib
-    lib = _lib.load()
+    lib = tuning_lib
     g = torch.Generator().manual_seed(80)
     M, N, K = 200, 136, 96
     x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)

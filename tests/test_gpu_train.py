@@ -220,11 +220,11 @@ def test_ragged_stack_equals_full_rows(B, T, S):
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,E", [(3, 4, 20, 197, 512), (2, 4, 5, 65, 64), (2, 2, 64, 300, 128), (1, 4, 33, 1000, 256)])
-def test_long_memory_attention_forward_chunked_vs_row_kernel(B, H, Tq, Tk, E):
+def test_long_memory_attention_forward_chunked_vs_row_kernel(B, H, Tq, Tk, E, tuning_lib):
     """Unmasked attention over a long memory (transformer.py:13-22 with mask None): the chunked kernel (keys streamed
     through LDS, running softmax) against fp64 and against the one-wavefront-per-row kernel, output and log-sum-exp."""
     from capdec import _lib, ops
-    lib = _lib.load()
+    lib = tuning_lib
     g = torch.Generator().manual_seed(Tk)
     q, k, v = (torch.randn(B * n, E, generator=g) for n in (Tq, Tk, Tk))
     dk = E // H
@@ -612,7 +612,7 @@ def test_cnn_rnn_trainer_matches_oracle_training_loop(graph):
 
 @pytest.mark.parametrize("B,H,Tq,Tk,dk,causal", [(5, 4, 20, 20, 128, True), (3, 2, 7, 5, 16, False), (2, 4, 50, 50, 128, True),
                                                 (4, 4, 20, 2, 64, False), (3, 4, 20, 197, 128, False), (2, 2, 9, 70, 32, False)])
-def test_attention_backward_one_pass_matches_two_pass(B, H, Tq, Tk, dk, causal):
+def test_attention_backward_one_pass_matches_two_pass(B, H, Tq, Tk, dk, causal, tuning_lib):
     """The LDS-resident backward for short sequences against the general two-pass kernels (both are also pinned by
     the golden gradients through the decoder tests, which use short sequences)."""
     from capdec import _lib, ops
@@ -627,7 +627,7 @@ def test_attention_backward_one_pass_matches_two_pass(B, H, Tq, Tk, dk, causal):
         ids[-1, -1] = 0
         ids32 = ids.to(torch.int32).cuda()
     o, lse = ops.attention(q, k, v, B, H, Tq, Tk, causal=causal, ids32=ids32, want_lse=True)
-    lib = _lib.load()
+    lib = tuning_lib
     one = ops.attention_bwd(q, k, v, do, lse, B, H, Tq, Tk, causal=causal, ids32=ids32, out=o)
     lib.capdec_attention_bwd_force_two_pass(1)
     try:

@@ -34,6 +34,26 @@ def test_library_exports_every_declared_symbol():
     assert lib.capdec_vocab_partial_elems(1000, 10000) == 1024 * 157      # rows in blocks of 64
 
 
+def test_tuning_build_exports_the_overrides_and_the_product_library_does_not():
+    """include/capdec_tuning.h: the process-wide kernel-selection switches live in libcapdec_tune.so only."""
+    import ctypes
+    from capdec import _lib
+    text = open(os.path.join(ROOT, "include", "capdec_tuning.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(capdec_[a-z0-9_]+)\s*\(", text)))
+    assert declared == _lib.tuning_symbols() and len(declared) == 5
+    product, tune = ctypes.CDLL(_lib.LIB_PATH), ctypes.CDLL(_lib.LIB_TUNE_PATH)
+    for name in declared:
+        assert hasattr(tune, name), f"{name} missing from the tuning build"
+        assert not hasattr(product, name), f"{name} must not be in the product library"
+    for name in header_functions():
+        assert hasattr(tune, name), f"{name} declared in capdec.h but not exported by the tuning build"
+    with _lib.tuning_build() as lib:
+        assert _lib.load() is lib
+        assert lib.capdec_gemm_force_config(7) == -22 and lib.capdec_gemm_force_config(11) == 0
+    assert _lib.load() is not lib
+
+
 def test_argument_validation_without_gpu():
     """Bad arguments are rejected before anything is launched (safe on a machine without a GPU)."""
     from capdec import _lib

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "image-captioning_amd"))
 import torch
 from capdec import _lib
 
-lib = _lib.load()
+lib = _lib.tuning_build().__enter__()      # libcapdec_tune.so: the build that has the tile overrides
 s = torch.cuda.current_stream().cuda_stream
 E = 512
 

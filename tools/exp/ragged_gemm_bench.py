@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "image-captioning_amd"))
 import torch
 from capdec import _lib, ops
 
-lib = _lib.load()
+lib = _lib.tuning_build().__enter__()      # libcapdec_tune.so: the build that has the tile overrides
 
 
 def timeit(fn, reps=40, warm=5):

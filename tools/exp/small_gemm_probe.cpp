@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "../../include/capdec.h"
+#include "../../include/capdec_tuning.h"   // link against libcapdec_tune.so
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %d at %d\n", (int)e, __LINE__); return 1; } } while (0)
 int main(int argc, char** argv) {
     const bool one = argc > 1;

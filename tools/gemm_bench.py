@@ -53,7 +53,7 @@ def main():
     x2 = rnd(10240, 512)
     tg = torch.randint(0, 10000, (10240,), generator=g).to(dev)
     cases.append(("vocab nll           M=10240 V=10000 K=512", 2.0 * 10240 * 10000 * 512, lambda: ops.vocab_nll(x2, W, b, tg)))
-    lib = _lib.load()
+    lib = _lib.tuning_build().__enter__()      # libcapdec_tune.so: the build that has the tile overrides
     print(f"{'case':48s} " + " ".join(f"{'cfg ' + str(c):>22s}" for c in (0, 11, 116, 32, 216)))
     for name, flops, fn in cases:
         cols = []

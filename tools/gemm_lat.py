@@ -12,7 +12,7 @@ from capdec import _lib
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.tuning_build().__enter__()      # libcapdec_tune.so: the build that has the tile overrides
     s = torch.cuda.current_stream().cuda_stream
     for M, N in ((1024, 512), (64, 64), (4096, 512)):
         for K in (32, 64, 128, 256, 512, 1024, 2048):

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "image-captioning_amd"))
 import torch
 from capdec import _lib, ops
 
-lib = _lib.load()
+lib = _lib.tuning_build().__enter__()      # libcapdec_tune.so: the build that has the tile overrides
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 11
 g = torch.Generator().manual_seed(0)
 rnd = lambda *s: torch.randn(*s, generator=g).cuda()
