@@ -435,13 +435,16 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None, 
     if not dy.is_contiguous():
         raise RuntimeError("capdec layernorm_bwd: dy must be contiguous")
     d_add = torch.empty((M, E), device=dy.device, dtype=torch.float32)
-    d_x = torch.empty_like(d_add) if p > 0 else None
+    # d_x always gets a tensor of its own, also when no mask is drawn (p == 0: the same values twice).  The caller
+    # accumulates further gradients into d_add in place on its main stream while the weight-gradient contraction that
+    # reads d_x may still be running on a second stream; one shared tensor would be overwritten under that reader.
+    d_x = torch.empty_like(d_add)
     _lib.check(lib.capdec_layernorm_bwd_rows(_chk(dy).data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                              _chk(gamma).data_ptr(), M, E, p, seed, _seed_ptr(seed_dev), d_add.data_ptr(),
                                              _ptr(d_x),
                                              _chk(dgamma).data_ptr(), _chk(dbeta).data_ptr(), _ptr(dxsum),
                                              _ptr(rows_dev), _stream()), "capdec_layernorm_bwd_rows")
-    return d_add, (d_x if p > 0 else d_add)
+    return d_add, d_x
 
 
 def attention_bwd(q, k, v, dout, lse, B, H, Tq, Tk, causal=False, ids32=None, dq=None, dk=None, dv=None, out=None):

@@ -56,40 +56,94 @@ def test_cfg1_cnn_rnn_greedy_b32_len20():
         assert gap <= REL * float(logits.abs().max()), f"row {b} step {s}: logit gap {gap:.3e}"
 
 
-def _oracle_grads(sd0, head, feats, caps, check, dtype):
-    sd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()).requires_grad_(k in check)
-          for k, v in sd0.items()}
-    enc, _ = head(sd, feats.to(dtype))
-    loss = R.caption_loss(R.decoder_forward(sd, enc, caps[:, :-1], H), caps[:, 1:])
+class _ReluTap:
+    """Records the argument of every torch.relu call (the feed-forward pre-activations of the oracle, layer by layer)."""
+
+    def __enter__(self):
+        self.pre = []
+        self._orig = torch.relu
+
+        def relu(x):
+            self.pre.append(x.detach())
+            return self._orig(x)
+
+        torch.relu = relu
+        return self
+
+    def __exit__(self, *exc):
+        torch.relu = self._orig
+
+
+def _oracle_grads(sd0, head, feats, caps, dtype):
+    sd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k and k != "positional_encoding.pe"]
+    for k in names:
+        sd[k].requires_grad_(True)
+    with _ReluTap() as tap:
+        enc, _ = head(sd, feats.to(dtype))
+        loss = R.caption_loss(R.decoder_forward(sd, enc, caps[:, :-1], H), caps[:, 1:])
     loss.backward()
-    return float(loss.detach()), {k: sd[k].grad.double() for k in check}
+    grads = {k: (sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])).double() for k in names}
+    return float(loss.detach()), grads, tap.pre
 
 
-def _train_step_vs_oracle(model, head, feats, caps, check):
-    """One CaptionTrainer step (dropout off) at full size: loss and a sample of gradients against the oracle's
-    forward + torch autograd on the CPU.
+AMBIGUOUS_RELU = 2e-6      # |pre-activation| below this fraction of the layer's largest counts as "at zero" in fp32
+                           # (a 512-term fp32 dot product of O(1) terms carries about that much rounding)
 
-    With 5 million ReLU inputs per layer a few pre-activations lie within fp32 rounding of zero, where the ReLU
-    mask of two correct fp32 implementations differs; one flipped element (m, j) moves row j of the fc1 weight
-    gradient (and, much less, everything upstream) by dh[m,j] * x[m,:], which can exceed 1e-4 of the tensor's
-    scale.  Hence: at least 99.5 % of every tensor's entries must be within 1e-4 of the scale, and no entry may be
-    off by more than 5e-3 of it (a wrong kernel is off everywhere, by far more)."""
+
+def _train_step_vs_oracle(model, head, feats, caps):
+    """One CaptionTrainer step (dropout off) at full size: the loss and EVERY parameter gradient against the oracle's
+    forward + torch autograd on the CPU, evaluated twice: in fp32 (the reference's arithmetic) and in fp64 (the exact
+    value, to rounding).  Per tensor, with tol = 1e-4 of the tensor's largest gradient, one of these must hold:
+
+      A. every entry of the HIP gradient is within tol of the fp64 gradient;
+      B. the reference's own fp32 evaluation is no closer to the exact value: the HIP gradient's largest error against
+         fp64 and its share of entries beyond tol are at most 1.25 x those of the fp32 oracle (sums of 10^4 rows whose
+         terms cancel -- W_q/W_k of the first layer, the BatchNorm head -- are conditioned worse than 1e-4 in fp32, on
+         the CPU as on the GPU);
+      C. (weight and bias of a feed-forward fc1 only) every entry beyond tol lies in a row j of the weight gradient for
+         which some position's pre-activation is within AMBIGUOUS_RELU of zero in the fp64 oracle: there two correct
+         fp32 evaluations may disagree on the ReLU mask, and one flipped element (m, j) moves row j of that gradient by
+         dh[m,j] * x[m,:].  Such rows must be few (under 15 % of the layer's units: 5 million pre-activations per
+         layer put a few dozen that close to zero).
+
+    A wrong kernel fails all three on whole tensors."""
     from capdec.trainer import CaptionTrainer
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    loss32, g32 = _oracle_grads(sd0, head, feats, caps, check, torch.float32)
+    loss32, g32, _ = _oracle_grads(sd0, head, feats, caps, torch.float32)
+    loss64, g64, pre64 = _oracle_grads(sd0, head, feats, caps, torch.float64)
     model = model.cuda()
     tr = CaptionTrainer(model, lr=1e-3)
     got = tr.step(feats.cuda(), caps.cuda())
-    assert abs(float(got.item()) - loss32) <= 1e-4 * abs(loss32)
-    big = max(float(g32[k].abs().max()) for k in check)
-    for k in check:
+    assert abs(float(got.item()) - loss64) <= 1e-5 * abs(loss64)
+    assert set(tr.grads) == set(g64)
+    big = max(float(g.abs().max()) for g in g64.values())
+    how = {"A": 0, "B": 0, "C": 0}
+    for k in sorted(g64):
         mine = tr.grads[k].detach().cpu().double()
-        scale = float(g32[k].abs().max())
-        err = (mine - g32[k]).abs()
+        scale = float(g64[k].abs().max())
         tol = REL * scale + 1e-6 * big
-        frac_bad = float((err > tol).double().mean())
-        assert frac_bad <= 5e-3 and float(err.max()) <= 5e-3 * scale + 1e-6 * big, \
-            f"{k}: {frac_bad:.2%} of entries beyond 1e-4, max err {float(err.max()):.3e}, scale {scale:.3e}"
+        e_hip, e_ref = (mine - g64[k]).abs(), (g32[k] - g64[k]).abs()
+        bad = e_hip > tol
+        if not bool(bad.any()):
+            how["A"] += 1
+            continue
+        frac_hip, frac_ref = float(bad.double().mean()), float((e_ref > tol).double().mean())
+        if float(e_hip.max()) <= 1.25 * float(e_ref.max()) and frac_hip <= 1.25 * frac_ref + 1e-5:
+            how["B"] += 1
+            continue
+        msg = (f"{k}: {frac_hip:.3%} of entries beyond 1e-4 of scale {scale:.3e} (fp32 oracle: {frac_ref:.3%}), "
+               f"max err {float(e_hip.max()):.3e} (fp32 oracle: {float(e_ref.max()):.3e})")
+        assert ".feed_forward.fc1." in k, msg
+        pre = pre64[int(k.split(".")[1])]
+        pre = pre.reshape(-1, pre.shape[-1])
+        near_zero = (pre.abs() < AMBIGUOUS_RELU * float(pre.abs().max())).any(dim=0)           # per unit j
+        assert float(near_zero.double().mean()) < 0.15, f"{k}: too many units count as ambiguous"
+        bad_rows = bad.reshape(bad.shape[0], -1).any(dim=1)
+        assert not bool((bad_rows & ~near_zero).any()), msg + " outside the rows fed by an ambiguous ReLU"
+        how["C"] += 1
+    assert how["A"] >= len(g64) // 2, how          # most tensors meet the bar outright
+    return how
 
 
 def test_cfg3_vit_attn_training_step_b512():
@@ -100,10 +154,7 @@ def test_cfg3_vit_attn_training_step_b512():
     g = torch.Generator().manual_seed(1234 + 3)
     feats = torch.rand(512, 1000, generator=g)
     caps = _captions(g, 512, 20, V)
-    check = ["fc2.bias", "decoder_layers.2.norm3.weight", "decoder_layers.0.self_attn.W_v.weight",
-             "decoder_layers.1.cross_attn.W_o.weight", "decoder_layers.1.feed_forward.fc1.weight",
-             "decoder_embedding.weight", "fc_vit.weight", "batchnorm.weight"]
-    _train_step_vs_oracle(m, lambda sd, f: R.head_single(sd, f, "fc_vit", training=True), feats, caps, check)
+    _train_step_vs_oracle(m, lambda sd, f: R.head_single(sd, f, "fc_vit", training=True), feats, caps)
 
 
 def test_cfg4_vitcnn_attn_training_step_and_decode():
@@ -114,10 +165,7 @@ def test_cfg4_vitcnn_attn_training_step_and_decode():
     g = torch.Generator().manual_seed(1234 + 4)
     feats = torch.rand(512, 3048, generator=g)
     caps = _captions(g, 512, 20, V)
-    check = ["fc2.bias", "decoder_layers.1.cross_attn.W_q.weight", "decoder_layers.1.cross_attn.W_k.weight",
-             "decoder_layers.0.cross_attn.W_v.bias", "decoder_layers.0.norm2.bias", "fc_vit.weight", "fc_cnn.weight",
-             "batchnorm.bias"]
-    _train_step_vs_oracle(m, lambda sd, f: R.head_pair(sd, f, "fc_vit", 1000, training=True), feats, caps, check)
+    _train_step_vs_oracle(m, lambda sd, f: R.head_pair(sd, f, "fc_vit", 1000, training=True), feats, caps)
     # decode with a fresh model (the step above moved the weights and the running statistics)
     torch.manual_seed(1)
     m = VITCNNAttentionModel(E, V, H, 2).eval()

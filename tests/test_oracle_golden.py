@@ -131,7 +131,7 @@ def test_f6_cnn_attn_head_eval_train_and_greedy():
     close(loss.detach(), fx["cnn_loss_train"])
     loss.backward()
     for k in ("fc1.weight", "batchnorm.weight", "batchnorm.bias", "decoder_embedding.weight", "fc2.weight"):
-        close(sdg[k].grad, fx["cnn_grad__" + k], rtol=2e-4, atol=1e-7)
+        close(sdg[k].grad, fx["cnn_grad__" + k], atol=1e-7)
     for k in ("running_mean", "running_var", "num_batches_tracked"):
         close(new["batchnorm." + k], fx["cnn_after__batchnorm." + k])
 
@@ -155,7 +155,7 @@ def test_f6_pair_head_eval_train():
     loss = R.caption_loss(logits, caps[:, 1:])
     loss.backward()
     for k in ("fc_vit.weight", "fc_vit.bias", "fc_cnn.weight", "batchnorm.weight"):
-        close(sdg[k].grad, fx["pair_grad__" + k], rtol=2e-4, atol=1e-7)
+        close(sdg[k].grad, fx["pair_grad__" + k], atol=1e-7)
 
 
 def test_f7_decoder_rnn_forward_grads_step_and_greedy():
@@ -171,7 +171,7 @@ def test_f7_decoder_rnn_forward_grads_step_and_greedy():
     loss.backward()
     for k, v in sdg.items():
         if "grad__" + k in fx and v.requires_grad:
-            close(v.grad if v.grad is not None else torch.zeros_like(v), fx["grad__" + k], rtol=2e-4, atol=1e-7)
+            close(v.grad if v.grad is not None else torch.zeros_like(v), fx["grad__" + k], atol=1e-7)
     h1, c1 = R.lstm_cell(t(fx["step_x"]), t(fx["step_h0"]), t(fx["step_c0"]),
                          sd["lstm.weight_ih_l0"], sd["lstm.weight_hh_l0"], sd["lstm.bias_ih_l0"], sd["lstm.bias_hh_l0"])
     close(h1, fx["step_h1"])
