@@ -62,25 +62,61 @@ def cpu_baseline(target_seconds=12.0):
                       f"{dt:.1f} s on {threads} torch CPU threads"}
 
 
-def train_bench(device, rank, world, steps, warmup, fence, note=lambda m: None, strong=False):
-    """BASELINE.json configs[2]: ViT-Attn teacher-forced training, B=512 per GPU (the reference's DDP draws a full
-    batch per rank), T=20, E=512, H=4, L=3, V=10000, features [512,1000] -> one memory row (reference-faithful).
-    One step = head + decoder forward, fused CE loss, backward, RCCL gradient all-reduce, Adam."""
-    from capdec.trainer import CaptionTrainer
-    from models.vitattn_model import VITAttentionModel
-    Bt, T, Lt = (512 // world if strong else 512), 20, 3      # strong: the 512-sample batch is sharded over the ranks
-    torch.manual_seed(0)
-    model = VITAttentionModel(E, V, H, Lt).to(device)
-    tr = CaptionTrainer(model, lr=1e-3, overlap=os.environ.get("CAPDEC_TRAIN_OVERLAP", "1") == "1")
-    note("trainer built")
-    g = torch.Generator().manual_seed(1234 + 3 + 1000 * rank)
-    feats = torch.rand(Bt, 1000, generator=g).to(device)
+def synthetic_captions(g, Bt, T, full_length=False):
+    """[Bt, T+1] int64: <SOS>, a body of 8..19 tokens (T-1 when full_length), <EOS>, <PAD> tail."""
     caps = torch.zeros(Bt, T + 1, dtype=torch.long)
     for b in range(Bt):
-        n = int(torch.randint(8, 20, (1,), generator=g))       # caption body length in [8,19]
+        n = T - 1 if full_length else int(torch.randint(8, 20, (1,), generator=g))       # caption body length
         caps[b, 0] = 1
         caps[b, 1:1 + n] = torch.randint(4, V, (n,), generator=g)
         caps[b, 1 + n] = 2
+    return caps
+
+
+def timed_gemm(x_rows, N, K, device, reps=20):
+    """Average duration (ms) of one [x_rows, K] x [N, K]^T contraction with bias, measured with HIP events on the
+    stream the kernel is launched on (torch's current stream)."""
+    from capdec import ops
+    x = torch.randn(x_rows, K, device=device)
+    W = torch.randn(N, K, device=device) * K ** -0.5
+    b = torch.zeros(N, device=device)
+    out = torch.empty(x_rows, N, device=device)
+    for _ in range(3):
+        ops.linear(x, W, b, out=out)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        ops.linear(x, W, b, out=out)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    return sum(ev[i].elapsed_time(ev[i + 1]) for i in range(reps)) / reps
+
+
+def train_bench(device, rank, world, steps, warmup, fence, note=lambda m: None, strong=False, batch=None, graph=None,
+                full_length=False, model_kind="vit", layers=3, with_roofline=False):
+    """BASELINE.json configs[2]: ViT-Attn teacher-forced training, B=512 per GPU (the reference's DDP draws a full
+    batch per rank), T=20, E=512, H=4, L=3, V=10000, features [512,1000] -> one memory row (reference-faithful).
+    One step = head + decoder forward, fused CE loss, backward, RCCL gradient all-reduce, Adam.
+    model_kind "vitcnn": BASELINE.json configs[3], ViTCNN-Attn, features [B,3048] -> two memory rows, L=2."""
+    from capdec.trainer import CaptionTrainer
+    T, Lt = 20, layers
+    Bt = batch if batch is not None else (512 // world if strong else 512)   # strong: the 512-sample batch is sharded
+    # small per-GPU batches are bound by the host's ~150 launches per step: replay the step as one HIP graph there
+    use_graph = (Bt <= 128) if graph is None else graph
+    torch.manual_seed(0)
+    if model_kind == "vitcnn":
+        from models.vitcnnattn_model import VITCNNAttentionModel
+        model, Dh, S = VITCNNAttentionModel(E, V, H, Lt).to(device), 3048, 2
+    else:
+        from models.vitattn_model import VITAttentionModel
+        model, Dh, S = VITAttentionModel(E, V, H, Lt).to(device), 1000, 1
+    tr = CaptionTrainer(model, lr=1e-3, overlap=os.environ.get("CAPDEC_TRAIN_OVERLAP", "1") == "1", graph=use_graph)
+    note("trainer built")
+    g = torch.Generator().manual_seed(1234 + 3 + 1000 * rank)
+    feats = torch.rand(Bt, Dh, generator=g).to(device)
+    caps = synthetic_captions(g, Bt, T, full_length)
+    lens = (caps[:, 1:] != 0).sum(1)                          # live rows of a sample: positions with a counted target
+    live_rows, live_sq = int(lens.sum()), int((lens * lens).sum())
     caps = caps.to(device)
     first = None
     for _ in range(warmup):
@@ -99,19 +135,123 @@ def train_bench(device, rank, world, steps, warmup, fence, note=lambda m: None, 
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     # algorithmic FLOPs per sample (2 per MAC): forward = L*(16TE^2 + 4SE^2 + 4T^2E + 4TSE) + 2TEV + 2DE; x3 for training
-    S = 1
-    f_fwd = Lt * (16 * T * E * E + 4 * S * E * E + 4 * T * T * E + 4 * T * S * E) + 2 * T * E * V + 2 * 1000 * E
+    f_fwd = Lt * (16 * T * E * E + 4 * S * E * E + 4 * T * T * E + 4 * T * S * E) + 2 * T * E * V + 2 * Dh * E
     tflops = 3.0 * f_fwd * world * Bt * steps / dt / 1e12
-    return {"metric": "teacher-forced train samples/sec", "value": world * Bt * steps / dt, "unit": "samples/s",
-            "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "scaling": "strong" if strong else "weak",
-            "config": {"workload": f"cfg3 ViT-Attn training, B={Bt}/GPU" + (" (512 sharded)" if strong else "") +
-                                   f", T={T}, E={E}, H={H}, L={Lt}, V={V}, "
-                                   "memory rows S=1, dropout 0.1, Adam lr 1e-3; caption bodies of 8-19 tokens, "
-                                   "so about 27 % of the positions are <PAD> tails (ignored by the loss; the decoder "
-                                   "stack and the vocabulary projection run on the live rows only)", "global_batch": world * Bt,
-                       "grad_allreduce_bytes": tr.grad_bytes()},
-            "algorithmic_tflops": tflops, "mfma_frac": tflops / (world * FP32_MFMA_PEAK_TFLOPS),
-            "loss_first": first, "loss_last": float(loss.item())}
+    # FLOPs the step actually executes on this rank's batch: only the live rows R (positions with a counted target) go
+    # through the stack and the vocabulary projection; with one memory row the cross-attention sub-layer is two
+    # B-row contractions per layer instead of four over all rows and two over the memory
+    R = live_rows
+    cross = 4 * Bt * E * E if S == 1 else (4 * R * E * E + 4 * Bt * S * E * E + 4 * R * S * E)
+    f_exec = Lt * (12 * R * E * E + cross + 4 * live_sq * E) + 2 * R * E * V + 2 * Bt * Dh * E
+    tflops_exec = 3.0 * f_exec * world * steps / dt / 1e12
+    name = "cfg4 ViTCNN-Attn" if model_kind == "vitcnn" else "cfg3 ViT-Attn"
+    out = {"metric": "teacher-forced train samples/sec", "value": world * Bt * steps / dt, "unit": "samples/s",
+           "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "scaling": "strong" if strong else "weak",
+           "config": {"workload": f"{name} training, B={Bt}/GPU" + (" (512 sharded)" if strong else "") +
+                                  f", T={T}, E={E}, H={H}, L={Lt}, V={V}, "
+                                  f"memory rows S={S}, dropout 0.1, Adam lr 1e-3; " +
+                                  ("full-length captions (no <PAD> tails)" if full_length else
+                                   "caption bodies of 8-19 tokens, so about 27 % of the positions are <PAD> tails "
+                                   "(ignored by the loss; the decoder stack and the vocabulary projection run on the "
+                                   "live rows only)"), "global_batch": world * Bt,
+                      "grad_allreduce_bytes": tr.grad_bytes(), "hip_graph": bool(use_graph),
+                      "live_rows_per_step": R, "rows_per_step": Bt * T},
+           "algorithmic_tflops": tflops, "mfma_frac": tflops / (world * FP32_MFMA_PEAK_TFLOPS),
+           "executed_tflops": tflops_exec, "executed_mfma_frac": tflops_exec / (world * FP32_MFMA_PEAK_TFLOPS),
+           "loss_first": first, "loss_last": float(loss.item())}
+    if with_roofline:
+        # dominant kernel family of the step: the three vocabulary-sized contractions (logits, their input gradient,
+        # the fc2 weight gradient), 2*R*E*V FLOP each; the forward one timed alone at the step's row count
+        rows = (R + 31) // 32 * 32
+        ms = timed_gemm(rows, V, E, device)
+        ach = 2.0 * rows * E * V / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": f"gemm_kernel (vocabulary projection of the training step, "
+                                                      f"{rows} x {V} x {E})",
+                           "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / FP32_MFMA_PEAK_TFLOPS, "avg_launch_ms": ms, "launches_timed": 20,
+                           "traffic": None, "algorithmic_bytes": 4.0 * (rows * E + V * E + V + rows * V)}
+    return out
+
+
+def decode_variant(kind, device, steps, warmup):
+    """Greedy decode (len 20, B=1024) of the two-memory-row models: ViTCNN-Attn (features [B,3048]) and YOLOCNN-Attn
+    (features [B,88484]: one rank's shard of the 8192-row batch of BASELINE.json configs[4]), with the feature head
+    timed on its own (its 86436-deep contraction is the largest single GEMM of the workloads)."""
+    from capdec import engine
+    torch.manual_seed(0)
+    if kind == "yolocnn":
+        from models.yolocnnattn_model import YOLOCNNAttentionModel
+        m, Dh, deep = YOLOCNNAttentionModel(E, V, H, 2).to(device).eval(), 88484, 86436
+    else:
+        from models.vitcnnattn_model import VITCNNAttentionModel
+        m, Dh, deep = VITCNNAttentionModel(E, V, H, 2).to(device).eval(), 3048, 1000
+    g = torch.Generator().manual_seed(1234 + 5)
+    feats = torch.rand(B, Dh, generator=g).to(device)
+
+    def dstep():
+        with torch.no_grad():
+            enc = m.encode_features(feats).view(B, 2, E)
+            return engine.tf_greedy_ids(m, enc, LEN, 1, 2, to_cpu=True)
+
+    for _ in range(warmup):
+        dstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    with torch.no_grad():
+        for i in range(steps):
+            m.encode_features(feats)
+            ev[i + 1].record()
+    torch.cuda.synchronize()
+    head_ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(steps)) / steps
+    head_tf = 2.0 * B * Dh * E / (head_ms * 1e-3) / 1e12
+    name = "cfg5 YOLOCNN-Attn (1024-row shard of the 8192 batch)" if kind == "yolocnn" else "cfg4 ViTCNN-Attn"
+    return {"workload": f"{name} greedy decode, features [{B},{Dh}] -> S=2, B={B}, len {LEN}, L=2", "value": B / dt,
+            "unit": "captions/s", "ms_per_step": dt * 1e3, "head_ms": head_ms, "head_tflops": head_tf,
+            "head_mfma_frac": head_tf / FP32_MFMA_PEAK_TFLOPS,
+            "head": f"two projections ({deep} and 2048 deep) + folded BatchNorm; the {deep}-deep one "
+                    + ("is split over workgroups with its partial sums added in a fixed order" if kind == "yolocnn"
+                       else "is a plain launch")}
+
+
+def cnn_rnn_variant(device, reps=50):
+    """BASELINE.json configs[0]: CNN-RNN greedy decode, B=32, len 20, E=256, hidden 512, V=5000 (cnnrnn_model.py:57-110):
+    the HIP path on the GPU, and the oracle's restatement of the reference loop on this host's CPU cores."""
+    from models.cnnrnn_model import CNNtoRNN
+    from oracle import decoder_ref as R
+    Er, Hd, Vr, Br = 256, 512, 5000, 32
+    torch.manual_seed(0)
+    m = CNNtoRNN(Er, Hd, Vr).eval()
+    sd = {k[len("decoderRNN."):]: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1234 + 1)
+    feats = torch.rand(Br, D, generator=g)
+    with torch.no_grad():
+        R.cnnrnn_greedy_ids(sd, feats, LEN)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 3.0:
+            R.cnnrnn_greedy_ids(sd, feats, LEN)
+            n += 1
+        cpu_dt = (time.perf_counter() - t0) / n
+    m = m.to(device)
+    fd = feats.to(device)
+    for _ in range(5):
+        m.caption_ids(fd, max_length=LEN)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.caption_ids(fd, max_length=LEN)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"workload": f"cfg1 CNN-RNN greedy decode, B={Br}, len {LEN}, E={Er}, hidden {Hd}, V={Vr}", "value": Br / dt,
+            "unit": "captions/s", "ms_per_step": dt * 1e3,
+            "cpu": {"value": Br / cpu_dt, "unit": "captions/s", "ms_per_step": cpu_dt * 1e3,
+                    "cores": torch.get_num_threads(), "kind": "port",
+                    "sample": f"{n} batches of {Br} in 3 s, oracle restatement of the reference loop"}}
 
 
 def variants_bench(device, steps=6, warmup=2):
@@ -123,6 +263,24 @@ def variants_bench(device, steps=6, warmup=2):
     from capdec.trainer import CaptionTrainer
     from models.vitattn_model import VITAttentionModel
     out = {}
+
+    def lean(r):
+        return {k: r[k] for k in ("value", "unit", "ms_per_step", "algorithmic_tflops", "mfma_frac", "executed_tflops",
+                                  "executed_mfma_frac") if k in r} | {"workload": r["config"]["workload"]}
+
+    fence1 = torch.cuda.synchronize
+    # ---- the strong-scaling shard of cfg3 on one GPU: 64 samples per step, replayed as one HIP graph ----
+    out["train_b64"] = lean(train_bench(device, 0, 1, 30, 4, fence1, batch=64, graph=True))
+    out["train_b64_launched"] = lean(train_bench(device, 0, 1, 30, 4, fence1, batch=64, graph=False))
+    # ---- cfg3 on full-length captions (every position has a counted target: nothing to skip) ----
+    out["train_full_length"] = lean(train_bench(device, 0, 1, steps, warmup, fence1, full_length=True))
+    # ---- BASELINE.json configs[3]: ViTCNN-Attn, two memory rows, L=2: training step and greedy decode ----
+    out["cfg4_train"] = lean(train_bench(device, 0, 1, steps, warmup, fence1, model_kind="vitcnn", layers=2))
+    out["cfg4_decode"] = decode_variant("vitcnn", device, steps, warmup)
+    # ---- BASELINE.json configs[4]: YOLOCNN-Attn, one rank's shard of the 8192-row batch ----
+    out["cfg5_shard"] = decode_variant("yolocnn", device, steps, warmup)
+    # ---- BASELINE.json configs[0]: CNN-RNN greedy, B=32, on the GPU and (the configuration as worded) on the CPU ----
+    out["cfg1_cnn_rnn_b32"] = cnn_rnn_variant(device)
     # ---- decode, S=64 grid: per-cell Linear(2048,E) (+ folded BatchNorm) then the cached greedy decoder ----
     model = build_model(device)
     S = 64
@@ -398,7 +556,7 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         del model
-        train = train_bench(device, rank, world, args.train_steps, args.warmup, fence, note)
+        train = train_bench(device, rank, world, args.train_steps, args.warmup, fence, note, with_roofline=rank == 0)
         watchdog.cancel()
         note("train timed")
         if rank == 0:
