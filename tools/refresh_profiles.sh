@@ -13,4 +13,9 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${t
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${tag}_fetch -o p -- python3 $R/bench.py --steps 1 --warmup 0 --train-steps 0 --no-cpu-baseline --no-variants > $O/${tag}_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${tag}_write -o p -- python3 $R/bench.py --steps 1 --warmup 0 --train-steps 0 --no-cpu-baseline --no-variants > $O/${tag}_write.log 2>&1
 timeout -k 10 300 python3 $R/tools/kernel_roofline.py > $O/${tag}_roofline.md 2> $O/${tag}_roofline.err
-echo done
+
+# MFMA utilisation: counters in a run of their own, durations from a trace-only run of the same workload
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${tag}_mfma_pmc -o p -- python3 $R/tools/mfma_workload.py > $O/${tag}_mfma_pmc.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_mfma_trace -o p -- python3 $R/tools/mfma_workload.py > $O/${tag}_mfma_trace.log 2>&1
+python3 $R/tools/mfma_util.py $O/${tag}_mfma_pmc/p_counter_collection.csv $O/${tag}_mfma_trace/p_kernel_trace.csv > $O/${tag}_mfma_util.md
+echo mfma done
