@@ -42,7 +42,7 @@ class CaptionTrainer:
     _SEED_HEAD, _SEED_DECODER = 0x2545F4914F6CDD1D, 0
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, pad_idx=0, overlap=True,
-                 skip_dead_rows=True, wgrad_stream=None, graph=False):
+                 skip_dead_rows=True, wgrad_stream=None, graph=False, exercise_collectives=False):
         """overlap=True: one async all-reduce per gradient segment, issued as soon as the backward pass has enqueued
         that segment; overlap=False: a single all-reduce of the whole flat gradient buffer after the backward pass.
         skip_dead_rows: run the Transformer stack on the live prefix of every caption only (the positions from a
@@ -54,7 +54,10 @@ class CaptionTrainer:
         also lets every kernel variant do its one-time set-up), the second is captured and replayed, later ones are
         replays (inputs are copied into fixed buffers first).  Same kernels in the same order as the launch-by-launch step, hence the
         same losses and parameters.  With more than one rank the gradient exchange stays outside the graph: forward +
-        backward replay as one graph, then one all-reduce of the flat gradient buffer, then Adam."""
+        backward replay as one graph, then one all-reduce of the flat gradient buffer, then Adam.
+        exercise_collectives: issue every broadcast / all-reduce even in a one-rank process group (where each is the
+        identity), so that the device-collective code path -- asynchronous work handles, segment boundaries, stream
+        ordering -- can run on a single GPU under RCCL."""
         self.model = model
         self.overlap = overlap
         self.skip_dead_rows = skip_dead_rows
@@ -67,7 +70,8 @@ class CaptionTrainer:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         # gloo has no dependable device collectives: stage through the host there (tests and rehearsals on one GPU);
         # RCCL ("nccl") reduces the device buffers in place
-        self.host_staged = self.world > 1 and dist.get_backend(process_group) == "gloo"
+        self.coll = self.world > 1 or (bool(exercise_collectives) and dist.is_available() and dist.is_initialized())
+        self.host_staged = self.coll and dist.get_backend(process_group) == "gloo"
         self._t, self._lr = 0, float(lr)
         self.rnn = getattr(model, "decoderRNN", None)          # CNN-RNN: the trainable module is the LSTM decoder
         core = self.rnn if self.rnn is not None else model
@@ -125,7 +129,7 @@ class CaptionTrainer:
             self.flat_buf[C:].copy_(bn.running_var)
             bn.running_mean.data = self.flat_buf[:C]
             bn.running_var.data = self.flat_buf[C:]
-        if self.world > 1:
+        if self.coll:
             self._bcast(self.flat_p)                              # DDP starts from rank 0's weights
             self._bcast(self.flat_buf)
 
@@ -136,7 +140,7 @@ class CaptionTrainer:
             dist.broadcast(h, src=0, group=self.pg)
             t.copy_(h)
         else:
-            cdist.broadcast_(t, src=0, group=self.pg)
+            dist.broadcast(t, src=0, group=self.pg)
 
     def _reduce_segment(self, i, works):
         if self._reduce_on:
@@ -223,12 +227,12 @@ class CaptionTrainer:
         Returns the rank-local loss as a 1-element device tensor (no host sync)."""
         self.model.train()
         self._t += 1
-        if self.world > 1:
+        if self.coll:
             self._bcast(self.flat_buf)
         if self.graph:
             return self._graph_step(feats, captions)
-        loss = self._forward_backward(feats, captions, reduce_inside=self.world > 1 and self.overlap)
-        if self.world > 1 and not self.overlap:
+        loss = self._forward_backward(feats, captions, reduce_inside=self.coll and self.overlap)
+        if self.coll and not self.overlap:
             self._all_reduce_whole()
         self._adam()
         return loss
@@ -239,7 +243,7 @@ class CaptionTrainer:
             # first sight of this shape: launch by launch (a real step; also every kernel variant's one-time set-up)
             self._graphs[key] = None
             loss = self._forward_backward(feats, captions, reduce_inside=False)
-            if self.world > 1:
+            if self.coll:
                 self._all_reduce_whole()
             self._adam()
             return loss
@@ -251,14 +255,14 @@ class CaptionTrainer:
             cap.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cap.graph):
                 cap.loss = self._forward_backward(cap.feats, cap.captions, reduce_inside=False)
-                if self.world == 1:
+                if not self.coll:
                     self._adam()
             self._graphs[key] = cap
         cap.feats.copy_(feats)
         cap.captions.copy_(captions)
         cap.graph.replay()
         loss = cap.loss.clone()            # the graph writes the same storage at every replay
-        if self.world > 1:
+        if self.coll:
             self._all_reduce_whole()
             self._adam()
         return loss

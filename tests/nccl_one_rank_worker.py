@@ -1,0 +1,54 @@
+"""Worker of tests/test_gpu_dist.py::test_rccl_one_rank_group_runs_the_device_collective_branch: a one-rank "nccl"
+(= RCCL) process group on GPU 0.  Four trainers start from the same weights and the same seed and take four steps on
+the same batches: no collectives at all; one asynchronous all-reduce per gradient segment issued during the backward
+pass; one all-reduce of the whole buffer after it; and the step replayed as a HIP graph with the all-reduce between the
+graph and Adam.  In a one-rank group every collective is the identity, so all four must agree.  argv: output .npz."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "image-captioning_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    from capdec import dist as cdist
+    from capdec.trainer import CaptionTrainer
+    from dist_train_worker import batch
+    from models.vitcnnattn_model import VITCNNAttentionModel
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    torch.manual_seed(7)
+    base = VITCNNAttentionModel(64, 90, 4, 2, dropout=0.1)
+    sd0 = {k: v.detach().clone() for k, v in base.state_dict().items()}
+    batches = [batch(r, B=16) for r in range(4)]
+    out = {}
+    modes = {"plain": dict(), "segments": dict(exercise_collectives=True, overlap=True),
+             "whole": dict(exercise_collectives=True, overlap=False),
+             "graph": dict(exercise_collectives=True, graph=True)}
+    for name, kw in modes.items():
+        m = VITCNNAttentionModel(64, 90, 4, 2, dropout=0.1)
+        m.load_state_dict(sd0)
+        m = m.to(dev)
+        torch.manual_seed(11)                       # the trainer draws its first dropout seed from this generator
+        tr = CaptionTrainer(m, lr=1e-3, **kw)
+        assert tr.coll == (name != "plain") and not tr.host_staged and tr.world == 1
+        losses = [float(tr.step(f.to(dev), c.to(dev)).item()) for f, c in batches]
+        out["loss_" + name] = np.asarray(losses)
+        out["p_" + name] = tr.flat_p.detach().cpu().numpy()
+    # the decode side's only exchange: ragged gather of token ids to rank 0
+    ids = torch.arange(12, dtype=torch.int64, device=dev).view(3, 4)
+    lens = torch.tensor([4, 2, 3], dtype=torch.int32, device=dev)
+    g_ids, g_len = cdist.gather_captions(ids, lens, 3)
+    assert torch.equal(g_ids, ids) and torch.equal(g_len, lens)
+    np.savez(sys.argv[1], **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
