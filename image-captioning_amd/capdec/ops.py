@@ -288,7 +288,7 @@ def vocab_nll(x, W, b, targets, ignore_index=0):
     lse = torch.empty(M, device=x.device, dtype=torch.float32)
     nll = torch.empty(M, device=x.device, dtype=torch.float32)
     sums = torch.zeros(2, device=x.device, dtype=torch.float32)
-    _lib.check(lib.capdec_nll_finalize(pm.data_ptr(), ps.data_ptr(), M, nt, x.data_ptr(), _row_stride(x, "x"),
+    _lib.check(lib.capdec_nll_finalize(pm.data_ptr(), ps.data_ptr(), M, V, x.data_ptr(), _row_stride(x, "x"),
                                        W.data_ptr(), b.data_ptr(), K, targets.contiguous().data_ptr(), ignore_index,
                                        lse.data_ptr(), nll.data_ptr(), sums.data_ptr(), _stream()),
                "capdec_nll_finalize")

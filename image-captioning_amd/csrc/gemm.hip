@@ -779,7 +779,8 @@ __global__ __launch_bounds__(256) void nll_finalize_kernel(const float* __restri
                                                            const float* __restrict__ W, const float* __restrict__ bias,
                                                            int K, const int64_t* __restrict__ targets,
                                                            int64_t ignore_index, float* __restrict__ lse_out,
-                                                           float* __restrict__ nll_out, float* __restrict__ loss_sum) {
+                                                           float* __restrict__ nll_out, float* __restrict__ loss_sum,
+                                                           int V) {
     __shared__ float red[2][4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float acc_nll = 0.f, acc_cnt = 0.f;
@@ -800,8 +801,11 @@ __global__ __launch_bounds__(256) void nll_finalize_kernel(const float* __restri
         float nll = 0.f;
         if (tg != ignore_index) {
             float d = 0.f;
-            for (int k = lane; k < K; k += 64) d += x[(int64_t)row * ldx + k] * W[tg * (int64_t)K + k];
-            d = wave_sum(d) + bias[tg];
+            // (a counted target outside the vocabulary is a caller error: its loss term is NaN, nothing is read there)
+            const bool in_range = tg >= 0 && tg < (int64_t)V;
+            if (in_range)
+                for (int k = lane; k < K; k += 64) d += x[(int64_t)row * ldx + k] * W[tg * (int64_t)K + k];
+            d = in_range ? wave_sum(d) + bias[tg] : NAN;
             nll = lse - d;
             acc_nll += nll;
             acc_cnt += 1.f;
@@ -1114,13 +1118,13 @@ int capdec_vocab_lse_partial(const float* x, int64_t ldx, const float* W, const 
     return vocab_reduce_launch(1, x, ldx, W, bias, M, V, K, part_max, part_sum, (hipStream_t)stream);
 }
 
-int capdec_nll_finalize(const float* part_max, const float* part_sum, int M, int ntiles, const float* x, int64_t ldx,
+int capdec_nll_finalize(const float* part_max, const float* part_sum, int M, int V, const float* x, int64_t ldx,
                         const float* W, const float* bias, int K, const int64_t* targets, int64_t ignore_index,
                         float* lse, float* nll, float* loss_sum, void* stream) {
-    CAPDEC_REQUIRE(part_max && part_sum && x && W && bias && targets && M >= 0 && ntiles >= 1 && K >= 1);
+    CAPDEC_REQUIRE(part_max && part_sum && x && W && bias && targets && M >= 0 && V >= 1 && K >= 1);
     if (M == 0) return 0;
     hipLaunchKernelGGL(nll_finalize_kernel, dim3((M + NLL_ROWS - 1) / NLL_ROWS), dim3(256), 0, (hipStream_t)stream, part_max, part_sum,
-                       M, ntiles, x, ldx, W, bias, K, targets, ignore_index, lse, nll, loss_sum);
+                       M, capdec_vocab_tiles(V), x, ldx, W, bias, K, targets, ignore_index, lse, nll, loss_sum, V);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

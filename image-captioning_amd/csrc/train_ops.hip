@@ -980,7 +980,11 @@ __global__ __launch_bounds__(256) void softmax_nll_grad_kernel(float* __restrict
         const float lse = wm + logf(sm);
         const int64_t tg = targets[row];
         const bool counted = tg != ignore_index;
-        const float tl = counted ? lr[tg] : 0.f;
+        // a counted target outside [0, V) is a caller error (torch's CrossEntropyLoss raises): no host can be told
+        // from here, so the row's loss term becomes NaN -- loud in the very next loss value -- instead of a read
+        // outside the row
+        const bool in_range = tg >= 0 && tg < (int64_t)V;
+        const float tl = counted ? (in_range ? lr[tg] : NAN) : 0.f;
         // the target logit is in a register before any lane overwrites the row
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (counted && lane == 0) acc += lse - tl;
@@ -1059,7 +1063,7 @@ __global__ __launch_bounds__(256, 2) void softmax_nll_grad_reg_kernel(float* __r
             v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, u * 1024, 0));
             if (lane + 64 * u >= n4) v[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         }
-        const float tl = counted ? lr[tg] : 0.f;
+        const float tl = counted ? ((tg >= 0 && tg < (int64_t)V) ? lr[tg] : NAN) : 0.f;   // out-of-range target: NaN loss, no stray read
         float mx = -INFINITY;
 #pragma unroll
         for (int u = 0; u < NV4; ++u) mx = fmaxf(mx, fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));

@@ -133,10 +133,12 @@ int capdec_vocab_argmax_static(const float* x, int64_t ldx, const float* W, cons
  *   replaces fc2 + criterion, transformer.py:137 + train.py:216,254-256.
  * Writes per-row lse[M] and picked target logit tgt_logit[M]; rows whose target == ignore_index
  * get nll contribution 0.  loss_sum[0] += sum nll, loss_sum[1] += number of valid rows (both must be
- * zeroed by the caller).  part_* are scratch of capdec_vocab_partial_elems(M, V) floats each. */
+ * zeroed by the caller).  part_* are scratch of capdec_vocab_partial_elems(M, V) floats each.  A counted target outside
+ * [0, V) is a caller error (torch raises there): its loss term, and with it the loss, comes out NaN; nothing outside
+ * W is read.  The same holds for capdec_softmax_nll_grad* below. */
 int capdec_vocab_lse_partial(const float* x, int64_t ldx, const float* W, const float* bias, int M, int V, int K,
                              float* part_max, float* part_sum, void* stream);
-int capdec_nll_finalize(const float* part_max, const float* part_sum, int M, int ntiles, const float* x,
+int capdec_nll_finalize(const float* part_max, const float* part_sum, int M, int V, const float* x,
                         int64_t ldx, const float* W, const float* bias, int K, const int64_t* targets,
                         int64_t ignore_index, float* lse, float* nll, float* loss_sum, void* stream);
 

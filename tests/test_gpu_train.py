@@ -680,3 +680,27 @@ def test_feature_store_batches_on_gpu(tmp_path):
         assert x.is_cuda and torch.equal(x.cpu(), feats[torch.from_numpy(r)])
         n += len(r)
     assert n == 1000
+
+
+def test_out_of_range_target_gives_nan_loss_and_no_stray_read():
+    """torch's CrossEntropyLoss raises on a target outside [0, V); these kernels cannot tell the host, so the loss of
+    that row -- and with it the batch loss -- is NaN, and nothing outside the logits row / the weight matrix is read."""
+    from capdec import ops
+    g = torch.Generator().manual_seed(4)
+    for V in (300, 7000, 10000, 12000):                 # two-pass, row-in-registers and streaming kernels
+        M = 40
+        tg = torch.randint(1, V, (M,), generator=g)
+        tg[3] = 0
+        good = torch.randn(M, V, generator=g)
+        sums, _ = ops.softmax_nll_grad_(good.clone().cuda(), tg.cuda(), 0)
+        assert bool(torch.isfinite(sums).all())
+        for bad in (V, V + 12345, -7):
+            t2 = tg.clone()
+            t2[5] = bad
+            sums, _ = ops.softmax_nll_grad_(good.clone().cuda(), t2.cuda(), 0)
+            assert bool(torch.isnan(sums[0])), (V, bad)
+    x, W, b = torch.randn(16, 64, generator=g).cuda(), torch.randn(500, 64, generator=g).cuda(), torch.zeros(500).cuda()
+    t3 = torch.randint(1, 500, (16,), generator=g)
+    assert bool(torch.isfinite(ops.vocab_nll(x, W, b, t3.cuda(), 0)[2]).all())
+    t3[2] = 500
+    assert bool(torch.isnan(ops.vocab_nll(x, W, b, t3.cuda(), 0)[2][0]))
