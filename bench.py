@@ -346,6 +346,39 @@ def variants_bench(device, steps=6, warmup=2):
     out["decode_softattn_lstm_grid64"] = {
         "workload": f"soft-attention LSTM greedy decode over a 64x2048 feature grid, B={B}, len {LEN}, E=512, hidden 512, "
                     f"attention 512, V={V}", "value": B / dt, "unit": "captions/s", "ms_per_step": dt * 1e3}
+    # ---- and its training step (forward, fused CE loss, backward through the attention and the LSTM, Adam); parity
+    #      unpinned like the decode above: gradients are checked against torch autograd on the same formulas ----
+    Bs = 512
+    sat.train()
+    gs = torch.Generator().manual_seed(1234 + 7)
+    caps_s = synthetic_captions(gs, Bs, 20).to(device)
+    grid_s = grid[:Bs].contiguous()
+    named = dict(sat.named_parameters())
+    grads = {k: torch.zeros_like(v) for k, v in named.items()}
+    moments = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in named.items()}
+    kstep = [0]
+
+    def sstep():
+        kstep[0] += 1
+        for gbuf in grads.values():
+            gbuf.zero_()
+        loss = AG.satt_train_step(sat, grid_s, caps_s, grads)
+        for k, prm in named.items():
+            ops.adam_step(prm.data.view(-1), grads[k].view(-1), moments[k][0].view(-1), moments[k][1].view(-1), 1e-3, kstep[0])
+        return loss
+
+    for _ in range(warmup):
+        sstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out["train_softattn_lstm_grid64"] = {
+        "workload": f"soft-attention LSTM training over a 64x2048 feature grid, B={Bs}, T=20, E=512, hidden 512, attention "
+                    f"512, V={V}: forward, CE loss, backward, Adam (no reference counterpart: parity unpinned)",
+        "value": Bs / dt, "unit": "samples/s", "ms_per_step": dt * 1e3}
     del sat, grid, feats
     # ---- training, S=197 tokens of width 768: Linear(768,E) per token, 3-layer decoder, loss, backward, Adam ----
     Bt, T, Lt, St, Dt = 512, 20, 3, 197, 768

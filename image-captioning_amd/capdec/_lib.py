@@ -146,6 +146,9 @@ _SIGNATURES = {
                                        c_size_t, _P, _P, _P, _P, _P]),
     "capdec_train_state_advance": (c_int, [_P, c_float, c_float, _P]),
     "capdec_adam_step_dev": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, _P, c_float, _P]),
+    "capdec_additive_attention_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, c_int64,
+                                              _P, _P, _P, _P]),
+    "capdec_axpy_rows": (c_int, [_P, c_int, c_float, c_int, c_int, _P, c_int, _P]),
     "capdec_topk_rows": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "capdec_vocab_argmax_static": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
 }

@@ -578,3 +578,146 @@ def decoder_rnn_forward(rnn, features, captions):
     x0 = rnn.image_input(features)                                       # head: autograd-connected in train mode
     named = dict(rnn.named_parameters())
     return _RnnLogitsFn.apply(rnn, captions, x0, *[named[n] for n in _RNN_PARAMS])
+
+
+# ---------------------------------------------------------------------------------------------
+# Soft-attention LSTM decoder (models/softattn_model.py; no counterpart in the reference): teacher-forced forward
+# and backward.  Built from the same step kernels as the CNN-RNN decoder above -- capdec_lstm_step /
+# capdec_lstm_step_bwd over a time-major tape -- plus the additive-attention operand: the LSTM input row is
+# [embedding | context] and the context, attended with the previous state, adds one more recurrent path
+# (h -> att_h -> scores -> context -> gates).  Without that operand the loops below are rnn_forward / rnn_backward.
+# ---------------------------------------------------------------------------------------------
+_SATT_PARAMS = ("fc_feat.weight", "fc_feat.bias", "att_f.weight", "att_f.bias", "att_h.weight", "att_h.bias", "att_v.weight",
+                "init_h.weight", "init_h.bias", "init_c.weight", "init_c.bias", "embed.weight", "lstm.weight_ih_l0",
+                "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0", "fc2.weight", "fc2.bias")
+
+
+def satt_prepare(m, feats):
+    """Memory rows, attention keys and initial state: (enc [B*S,E], pf [B*S,A], mean [B,E], h0, c0)."""
+    B, S, D = feats.shape
+    enc = ops.linear(feats.reshape(B * S, D).contiguous(), m.fc_feat.weight, m.fc_feat.bias)
+    pf = ops.linear(enc, m.att_f.weight, m.att_f.bias)
+    mean = ops.axpy_rows(ops.group_sum(enc, S), 1.0 / S)
+    h0 = ops.linear(mean, m.init_h.weight, m.init_h.bias)
+    c0 = ops.linear(mean, m.init_c.weight, m.init_c.bias)
+    return enc, pf, mean, h0, c0
+
+
+def satt_forward(m, feats, ids):
+    """Teacher-forced pass keeping what the backward needs.  feats [B,S,D], ids [B,T] int64.
+    Returns (h [T*B, Hd] time-major outputs, tape)."""
+    B, S, D = feats.shape
+    T = ids.shape[1]
+    t = Tape()
+    t.feats2d = feats.reshape(B * S, D).contiguous()
+    t.enc, t.pf, t.mean, h0, c0 = satt_prepare(m, feats)
+    E, A, Hd = t.enc.shape[1], t.pf.shape[1], h0.shape[1]
+    dev = feats.device
+    t.B, t.S, t.T, t.E, t.A, t.Hd = B, S, T, E, A, Hd
+    t.ids_tm = ids.t().contiguous()
+    t.x = torch.empty((T * B, 2 * E), device=dev, dtype=torch.float32)            # [emb | ctx] rows, time-major
+    t.h = torch.empty(((T + 1) * B, Hd), device=dev, dtype=torch.float32)         # block 0 = h0, block s+1 = after step s
+    t.c = torch.empty(((T + 1) * B, Hd), device=dev, dtype=torch.float32)
+    t.g = torch.empty((T * B, 4 * Hd), device=dev, dtype=torch.float32)
+    t.u = torch.empty((T * B, A), device=dev, dtype=torch.float32)
+    t.alpha = torch.empty((T * B, S), device=dev, dtype=torch.float32)
+    t.h[:B].copy_(h0)
+    t.c[:B].copy_(c0)
+    if T > 0:
+        emb = ops.embed_pe(t.ids_tm, m.embed.weight, None)                         # [T*B, E]
+        t.x[:, :E].copy_(emb)
+    w = (m.lstm.weight_ih_l0, m.lstm.weight_hh_l0, m.lstm.bias_ih_l0, m.lstm.bias_hh_l0)
+    v = m.att_v.weight.reshape(-1)
+    enc3, pf3 = t.enc.view(B, S, E), t.pf.view(B, S, A)
+    for s in range(T):
+        a, b, c = s * B, (s + 1) * B, (s + 2) * B
+        ops.linear(t.h[a:b], m.att_h.weight, m.att_h.bias, out=t.u[a:b])
+        ops.additive_attention(t.u[a:b], pf3, v, enc3, t.x[a:b, E:], t.alpha[a:b])
+        ops.lstm_step_into(t.x[a:b], t.h[a:b], t.c[a:b], *w, t.h[b:c], t.c[b:c], t.g[a:b])
+    return t.h[B:], t
+
+
+def satt_backward(m, t, dh_out, grads):
+    """Backward of ``satt_forward``: dh_out [T*B, Hd] time-major.  Fills every gradient except fc2's."""
+    B, S, T, E, A, Hd = t.B, t.S, t.T, t.E, t.A, t.Hd
+    dev = dh_out.device
+    w_ih, w_hh, b_ih, b_hh = m.lstm.weight_ih_l0, m.lstm.weight_hh_l0, m.lstm.bias_ih_l0, m.lstm.bias_hh_l0
+    v = m.att_v.weight.reshape(-1)
+    enc3, pf3 = t.enc.view(B, S, E), t.pf.view(B, S, A)
+    dg = torch.empty_like(t.g)
+    dx = torch.empty_like(t.x)
+    du = torch.empty_like(t.u)
+    dpf = torch.zeros_like(t.pf)
+    denc = torch.zeros_like(t.enc)
+    dvb = torch.zeros((B, A), device=dev, dtype=torch.float32)
+    dh_rec, dc = None, None
+    for s in range(T - 1, -1, -1):
+        a, b, c = s * B, (s + 1) * B, (s + 2) * B
+        dc = ops.lstm_step_bwd(t.g[a:b], t.c[a:b], t.c[b:c], dh_out[a:b], dh_rec, dc, dg[a:b])
+        ops.gemm_raw(dg[a:b], w_ih, dx[a:b], B, 2 * E, 4 * Hd, 4 * Hd, w_ih.stride(0), _lib.GEMM_TQ)     # d[emb | ctx]
+        ops.additive_attention_bwd(t.u[a:b], pf3, v, enc3, t.alpha[a:b], dx[a:b, E:], du[a:b], dpf, denc, dvb)
+        dh_rec = ops.linear_dgrad(dg[a:b], w_hh)
+        ops.linear_dgrad(du[a:b], m.att_h.weight, accum=dh_rec)
+    if dh_rec is None:                                             # no steps: the state received no gradient
+        dh_rec = torch.zeros((B, Hd), device=dev, dtype=torch.float32)
+        dc = torch.zeros_like(dh_rec)
+    # LSTM and attention-query weights: single contractions over all steps of the tape
+    ops.linear_wgrad(dg, t.x, out=_new(grads, "lstm.weight_ih_l0", w_ih))
+    ops.linear_wgrad(dg, t.h[:T * B], out=_new(grads, "lstm.weight_hh_l0", w_hh))
+    ops.colsum(dg, _new(grads, "lstm.bias_ih_l0", b_ih))
+    ops.colsum(dg, _new(grads, "lstm.bias_hh_l0", b_hh))
+    ops.linear_wgrad(du, t.h[:T * B], out=_new(grads, "att_h.weight", m.att_h.weight))
+    ops.colsum(du, _new(grads, "att_h.bias", m.att_h.bias))
+    ops.colsum(dvb, _new(grads, "att_v.weight", m.att_v.weight).view(-1))
+    demb = _new(grads, "embed.weight", m.embed.weight)
+    if T > 0:
+        ops.embed_bwd(t.ids_tm.view(-1), dx[:, :E].contiguous(), demb)
+    # initial state: h0 = init_h(mean), c0 = init_c(mean), mean = sum_s enc / S
+    dmean = _lin_bwd(grads, "init_h", m.init_h, dh_rec, t.mean)
+    _lin_bwd(grads, "init_c", m.init_c, dc, t.mean, accum=dmean)
+    ops.axpy_rows(dmean, 1.0 / S, x_div=S, out=denc, accumulate=True)
+    # attention keys pf = att_f(enc), memory rows enc = fc_feat(feats)
+    _lin_bwd(grads, "att_f", m.att_f, dpf, t.enc, accum=denc)
+    _lin_bwd(grads, "fc_feat", m.fc_feat, denc, t.feats2d, need_dx=False)
+
+
+class _SattLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m, feats, captions, *params):
+        h, tape = satt_forward(m, feats.detach(), captions)
+        B, T = captions.shape
+        logits_tm = ops.linear(h, m.fc2.weight, m.fc2.bias)
+        ctx.m, ctx.tape, ctx.h = m, tape, h
+        return logits_tm.view(T, B, -1).transpose(0, 1)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m, tape = ctx.m, ctx.tape
+        grads = {}
+        V = dlogits.shape[-1]
+        d_tm = dlogits.transpose(0, 1).contiguous().view(-1, V)
+        dh = _lin_bwd(grads, "fc2", m.fc2, d_tm, ctx.h)
+        satt_backward(m, tape, dh, grads)
+        return (None, None, None) + tuple(grads.get(n) for n in _SATT_PARAMS)
+
+
+def satt_logits(m, feats, captions):
+    """Autograd-connected teacher-forced logits [B,T,V] of the soft-attention LSTM decoder."""
+    if not feats.is_cuda or not captions.is_cuda:
+        raise RuntimeError("capdec: inputs must live on the GPU (HIP); there is no CPU path")
+    if feats.requires_grad:
+        raise NotImplementedError("capdec: gradients w.r.t. the backbone features are not part of the hot path")
+    named = dict(m.named_parameters())
+    return _SattLogitsFn.apply(m, feats, captions, *[named[n] for n in _SATT_PARAMS])
+
+
+def satt_train_step(m, feats, captions, grads, pad_idx=0):
+    """Forward, CrossEntropyLoss(ignore_index=<PAD>) and backward with the fused loss path (no [B,T,V] autograd
+    tensor): captions [B,T+1].  Returns the loss (1-element device tensor); ``grads`` receives every gradient."""
+    ids = captions[:, :-1].contiguous()
+    tgt = captions[:, 1:].contiguous()
+    h, tape = satt_forward(m, feats, ids)
+    loss, saved = vocab_loss(m, h, tgt.t().contiguous(), pad_idx)                 # rows of h are time-major
+    dh = vocab_loss_bwd(m, h, saved, grads)
+    satt_backward(m, tape, dh, grads)
+    return loss

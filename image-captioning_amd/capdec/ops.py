@@ -677,3 +677,61 @@ def adam_step_dev(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scal
     _lib.check(lib.capdec_adam_step_dev(_chk(p).data_ptr(), _chk(g).data_ptr(), _chk(m).data_ptr(), _chk(v).data_ptr(),
                                         p.numel(), beta1, beta2, eps, state.buf.data_ptr(), grad_scale, _stream()),
                "capdec_adam_step_dev")
+
+
+# ---------------------------------------------------------------------------------------------
+# additive attention (soft-attention LSTM decoder; no counterpart in the reference)
+# ---------------------------------------------------------------------------------------------
+def additive_attention(u, pf, v, enc, ctx_out, alpha_out=None):
+    """u [B,A] (row stride free), pf [B,S,A], v [A], enc [B,S,E] -> ctx_out [B,E] (a view with unit column stride, e.g.
+    the right half of the LSTM's [emb | ctx] input rows); alpha_out [B,S] optional."""
+    lib = _lib.load()
+    B, S, A = pf.shape
+    E = enc.shape[2]
+    for name, t in (("pf", pf), ("enc", enc), ("v", v)):
+        if not _chk(t, name=name).is_contiguous():
+            raise RuntimeError(f"capdec additive_attention: {name} must be contiguous")
+    if alpha_out is not None and (alpha_out.shape != (B, S) or not alpha_out.is_contiguous()):
+        raise RuntimeError("capdec additive_attention: alpha_out must be a contiguous [B,S] tensor")
+    _lib.check(lib.capdec_additive_attention(_chk(u, name="u").data_ptr(), _row_stride(u, "u"), pf.data_ptr(), v.data_ptr(),
+                                             enc.data_ptr(), B, S, A, E, _chk(ctx_out, name="ctx_out").data_ptr(),
+                                             _row_stride(ctx_out, "ctx_out"), _ptr(alpha_out), _stream()),
+               "capdec_additive_attention")
+    return ctx_out
+
+
+def additive_attention_bwd(u, pf, v, enc, alpha, dctx, du_out, dpf_acc, denc_acc, dvb_acc):
+    """Backward of one ``additive_attention`` step: writes du_out [B,A]; accumulates into dpf_acc [B,S,A], denc_acc
+    [B,S,E] and dvb_acc [B,A] (per-sample partial of the gradient of v)."""
+    lib = _lib.load()
+    B, S, A = pf.shape
+    E = enc.shape[2]
+    for name, t in (("pf", pf), ("enc", enc), ("v", v), ("alpha", alpha), ("dpf", dpf_acc), ("denc", denc_acc), ("dvb", dvb_acc)):
+        if not _chk(t, name=name).is_contiguous():
+            raise RuntimeError(f"capdec additive_attention_bwd: {name} must be contiguous")
+    if dpf_acc.numel() != B * S * A or denc_acc.numel() != B * S * E or dvb_acc.numel() != B * A or alpha.numel() != B * S:
+        raise RuntimeError("capdec additive_attention_bwd: accumulator shapes do not match [B,S,A] / [B,S,E] / [B,A]")
+    _lib.check(lib.capdec_additive_attention_bwd(_chk(u, name="u").data_ptr(), _row_stride(u, "u"), pf.data_ptr(),
+                                                 v.data_ptr(), enc.data_ptr(), alpha.data_ptr(),
+                                                 _chk(dctx, name="dctx").data_ptr(), _row_stride(dctx, "dctx"), B, S, A, E,
+                                                 _chk(du_out, name="du").data_ptr(), _row_stride(du_out, "du"),
+                                                 dpf_acc.data_ptr(), denc_acc.data_ptr(), dvb_acc.data_ptr(), _stream()),
+               "capdec_additive_attention_bwd")
+    return du_out
+
+
+def axpy_rows(x, scale, x_div=1, out=None, rows=None, accumulate=False):
+    """out[r,:] = (accumulate ? out[r,:] : 0) + scale * x[r // x_div, :] for r < rows (default: x rows * x_div)."""
+    lib = _lib.load()
+    _chk(x, name="x")
+    E = x.shape[1]
+    M = x.shape[0] * x_div if rows is None else rows
+    if out is None:
+        if accumulate:
+            raise RuntimeError("capdec axpy_rows: accumulate needs an output tensor")
+        out = torch.empty((M, E), device=x.device, dtype=torch.float32)
+    if not x.is_contiguous() or not out.is_contiguous() or out.shape != (M, E):
+        raise RuntimeError("capdec axpy_rows: contiguous [rows,E] tensors expected")
+    _lib.check(lib.capdec_axpy_rows(x.data_ptr(), x_div, float(scale), M, E, _chk(out, name="out").data_ptr(),
+                                    1 if accumulate else 0, _stream()), "capdec_axpy_rows")
+    return out

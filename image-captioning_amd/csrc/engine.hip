@@ -132,6 +132,98 @@ __global__ __launch_bounds__(256) void additive_attention_kernel(const float* __
         for (int s = threadIdx.x; s < S; s += 256) alpha[(int64_t)b * S + s] = expf(sc[s] - mx) / sm;
 }
 
+// Backward of additive_attention_kernel for one decode/training step.  One workgroup per sample; enc and pf are read
+// once, the accumulators denc / dpf / dvb (which collect the contributions of all steps of a caption) are read and
+// written once.  With a = alpha (saved by the forward pass), g = dctx:
+//   dalpha_s = g . enc_s ;  denc_s += a_s g ;  de_s = a_s (dalpha_s - sum_s' a_s' dalpha_s')
+//   th = tanh(u + pf_s) ;  dz = de_s v (1 - th^2) ;  du = sum_s dz ;  dpf_s += dz ;  dvb += sum_s de_s th
+// dvb is per sample ([B,A]; its column sum over the batch is the gradient of v), so that no two workgroups add to
+// the same address.
+__global__ __launch_bounds__(256) void additive_attention_bwd_kernel(const float* __restrict__ u, int64_t ldu,
+                                                                     const float* __restrict__ pf,
+                                                                     const float* __restrict__ v,
+                                                                     const float* __restrict__ enc,
+                                                                     const float* __restrict__ alpha,
+                                                                     const float* __restrict__ dctx, int64_t lddctx,
+                                                                     int S, int A, int E, float* __restrict__ du,
+                                                                     int64_t lddu, float* __restrict__ dpf,
+                                                                     float* __restrict__ denc, float* __restrict__ dvb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [S] alpha, [S] dalpha -> de, [NSG][A] du, [NSG][A] dv
+    const int S4 = ((S + 3) / 4) * 4;
+    float* al = lds;
+    float* de = lds + S4;
+    float* pdu = lds + 2 * S4;
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ncol = A / 4;                                        // float4 columns of the attention space
+    const int nsg = ncol >= 256 ? 1 : 256 / ncol;                  // row groups working on the same columns
+    float* pdv = pdu + nsg * A;
+    const float* ub = u + (int64_t)b * ldu;
+    const float* pfb = pf + (int64_t)b * S * A;
+    const float* eb = enc + (int64_t)b * S * E;
+    const float* gb = dctx + (int64_t)b * lddctx;
+    float* dpfb = dpf + (int64_t)b * S * A;
+    float* dencb = denc + (int64_t)b * S * E;
+    for (int s = threadIdx.x; s < S; s += 256) al[s] = alpha[(int64_t)b * S + s];
+    __syncthreads();
+    // pass 1 over enc: dalpha_s, and denc_s += alpha_s g in the same sweep
+    for (int s = wave; s < S; s += 4) {
+        const float a = al[s];
+        float d = 0.f;
+        for (int c = lane; c < E / 4; c += 64) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gb + 4 * c);
+            const f32x4 e4 = *reinterpret_cast<const f32x4*>(eb + (int64_t)s * E + 4 * c);
+            d += g4[0] * e4[0] + g4[1] * e4[1] + g4[2] * e4[2] + g4[3] * e4[3];
+            f32x4* o = reinterpret_cast<f32x4*>(dencb + (int64_t)s * E + 4 * c);
+            *o = *o + g4 * a;
+        }
+        d = wave_sum(d);
+        if (lane == 0) de[s] = d;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int s = lane; s < S; s += 64) dot += al[s] * de[s];
+    dot = wave_sum(dot);                                            // every wavefront computes the same sum
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += 256) de[s] = al[s] * (de[s] - dot);
+    __syncthreads();
+    // pass 2 over pf: a thread owns float4 columns c, c + 256 * ..., and the rows s = sg, sg + nsg, ...
+    const int sg = threadIdx.x / ncol < nsg ? threadIdx.x / ncol : nsg;      // (threads beyond nsg * ncol idle when ncol does not divide 256)
+    const int c0 = threadIdx.x - sg * ncol;
+    if (sg < nsg) {
+        for (int c = c0; c < ncol; c += (ncol >= 256 ? 256 : ncol)) {
+            const f32x4 u4 = *reinterpret_cast<const f32x4*>(ub + 4 * c);
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(v + 4 * c);
+            f32x4 adu = {0.f, 0.f, 0.f, 0.f}, adv = {0.f, 0.f, 0.f, 0.f};
+            for (int s = sg; s < S; s += nsg) {
+                const f32x4 p4 = *reinterpret_cast<const f32x4*>(pfb + (int64_t)s * A + 4 * c);
+                const float d = de[s];
+                f32x4 dz;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float th = tanhf(u4[k] + p4[k]);
+                    dz[k] = d * v4[k] * (1.f - th * th);
+                    adv[k] += d * th;
+                }
+                adu += dz;
+                f32x4* o = reinterpret_cast<f32x4*>(dpfb + (int64_t)s * A + 4 * c);
+                *o = *o + dz;
+            }
+            *reinterpret_cast<f32x4*>(pdu + sg * A + 4 * c) = adu;
+            *reinterpret_cast<f32x4*>(pdv + sg * A + 4 * c) = adv;
+        }
+    }
+    __syncthreads();
+    for (int a = threadIdx.x; a < A; a += 256) {
+        float su = 0.f, sv = 0.f;
+        for (int g = 0; g < nsg; ++g) {
+            su += pdu[g * A + a];
+            sv += pdv[g * A + a];
+        }
+        du[(int64_t)b * lddu + a] = su;
+        dvb[(int64_t)b * A + a] += sv;
+    }
+}
+
 // ---- beam search bookkeeping (transformer.py:177-244, cnnrnn_model.py:112-209) --------------------------------
 constexpr int BEAM_MAX_W = 8;
 
@@ -1263,6 +1355,25 @@ int capdec_additive_attention(const float* u, int64_t ldu, const float* pf, cons
     CAPDEC_REQUIRE(smem <= 64 * 1024);
     hipLaunchKernelGGL(additive_attention_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, u, ldu, pf, v, enc, S, A, E,
                        ctx, ldctx, alpha);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_additive_attention_bwd(const float* u, int64_t ldu, const float* pf, const float* v, const float* enc,
+                                  const float* alpha, const float* dctx, int64_t lddctx, int B, int S, int A, int E,
+                                  float* du, int64_t lddu, float* dpf, float* denc, float* dvb, void* stream) {
+    CAPDEC_REQUIRE(u && pf && v && enc && alpha && dctx && du && dpf && denc && dvb && B >= 0 && S >= 1 && S <= 4096 &&
+                   A >= 4 && A % 4 == 0 && E >= 4 && E % 4 == 0);
+    CAPDEC_REQUIRE(ldu >= A && lddu >= A && lddctx >= E && ldu % 4 == 0 && lddctx % 4 == 0);
+    if (!capdec_aligned16(u) || !capdec_aligned16(pf) || !capdec_aligned16(v) || !capdec_aligned16(enc) ||
+        !capdec_aligned16(dctx) || !capdec_aligned16(dpf) || !capdec_aligned16(denc))
+        return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    const int ncol = A / 4, nsg = ncol >= 256 ? 1 : 256 / ncol;
+    const size_t smem = (2 * (size_t)((S + 3) / 4) * 4 + 2 * (size_t)nsg * A) * sizeof(float);
+    CAPDEC_REQUIRE(smem <= 64 * 1024);
+    hipLaunchKernelGGL(additive_attention_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, u, ldu, pf, v, enc, alpha,
+                       dctx, lddctx, S, A, E, du, lddu, dpf, denc, dvb);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

@@ -303,6 +303,20 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict_
     }
 }
 
+// y[r,:] = (accumulate ? y[r,:] : 0) + scale * x[r / x_div, :]   (a mean from a sum; a per-sample row added to
+// each of its S memory rows)
+__global__ void axpy_rows_kernel(const float* __restrict__ x, int x_div, float scale, int M, int E,
+                                 float* __restrict__ y, int accumulate) {
+    const int nv = E / 4;
+    const int64_t n = (int64_t)M * nv;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / nv), c = (int)(idx - (int64_t)r * nv);
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x + (int64_t)(r / x_div) * E)[c] * scale;
+        f32x4* o = reinterpret_cast<f32x4*>(y + (int64_t)r * E) + c;
+        *o = accumulate ? *o + xv : xv;
+    }
+}
+
 // ---- embedding backward: demb[ids[r], :] += dx[r, :] ----------------------------------------------
 // Same-address float atomics serialise, and a few ids are very frequent: the reference's vocabulary reserves
 // ids 0..3 for <PAD>/<SOS>/<EOS>/<UNK> (get_loader.py:28-29), <SOS> opens every caption and <PAD> fills the
@@ -1315,6 +1329,16 @@ int capdec_group_sum(const float* x, int G, int T, int E, float* out, void* stre
     if (!capdec_aligned16(x) || !capdec_aligned16(out)) return CAPDEC_EALIGN;
     if (G == 0) return 0;
     hipLaunchKernelGGL(group_sum_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, G, T, E, out, nullptr);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_axpy_rows(const float* x, int x_div, float scale, int M, int E, float* y, int accumulate, void* stream) {
+    CAPDEC_REQUIRE(x && y && x_div >= 1 && M >= 0 && E >= 4 && E % 4 == 0);
+    if (!capdec_aligned16(x) || !capdec_aligned16(y)) return CAPDEC_EALIGN;
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(axpy_rows_kernel, dim3(grid_for((int64_t)M * E / 4)), dim3(256), 0, (hipStream_t)stream, x, x_div, scale,
+                       M, E, y, accumulate);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

@@ -3,7 +3,8 @@
 NOT part of the reference repository: its "Attn" models are Transformer decoders.  The model is provided because
 the project's goals name "a fused LSTM cell with additive attention over encoder tiles"; there is no reference
 behaviour to match, so the formulas below ARE the definition (checked against a plain-PyTorch evaluation of the same
-formulas in the tests).  Inference and greedy decoding only.
+formulas in the tests, gradients against torch autograd on that evaluation).  Teacher-forced forward / backward and
+greedy decoding.
 
     enc   = fc_feat(feats)                         [B,S,E]    per-cell / per-token projection
     pf    = att_f(enc)                             [B,S,A]    once per caption
@@ -40,21 +41,17 @@ class SoftAttentionLSTMDecoder(nn.Module):
     def _prepare(self, feats):
         if not feats.is_cuda or feats.dtype != torch.float32:
             raise RuntimeError("capdec: features must be an fp32 tensor on the GPU (HIP); there is no CPU path")
+        from capdec import autograd as AG
         B, S, D = feats.shape
-        enc = ops.linear(feats.reshape(B * S, D).contiguous(), self.fc_feat.weight, self.fc_feat.bias)
-        pf = ops.linear(enc, self.att_f.weight, self.att_f.bias)
-        total = ops.group_sum(enc, S)                                        # [B,E] sum over the S rows
-        E = enc.shape[1]
-        inv = torch.full((self.init_h.out_features,), 1.0 / S, device=feats.device)
-        # (sum W^T) / S + b == mean W^T + b : the 1/S rides in the contraction's per-column scale/shift epilogue
-        h0 = ops.linear(total, self.init_h.weight, None, scale=inv, shift=self.init_h.bias)
-        c0 = ops.linear(total, self.init_c.weight, None, scale=inv, shift=self.init_c.bias)
-        return enc.view(B, S, E), pf.view(B, S, -1), h0, c0
+        enc, pf, _, h0, c0 = AG.satt_prepare(self, feats)
+        return enc.view(B, S, -1), pf.view(B, S, -1), h0, c0
 
     def forward(self, feats, captions):
-        """feats [B,S,D], captions [B,T] -> logits [B,T,V] (inference: no autograd graph is built)."""
+        """feats [B,S,D], captions [B,T] -> logits [B,T,V]; autograd-connected when gradients are enabled (forward and
+        backward both on the HIP kernels, see capdec.autograd.satt_forward / satt_backward)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("SoftAttentionLSTMDecoder is inference-only: call it under torch.no_grad()")
+            from capdec import autograd as AG
+            return AG.satt_logits(self, feats, captions)
         enc, pf, h, c = self._prepare(feats)
         B, S, E = enc.shape
         T = captions.shape[1]

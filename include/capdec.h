@@ -233,6 +233,8 @@ int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* s
 int capdec_colsum_rows(const float* x, int64_t ldx, int M, int N, float* out, const int32_t* rows_dev, void* stream);
 /* out[g,:] = sum over t < T of x[g*T + t, :]  (gradient of a row that was broadcast over T positions) */
 int capdec_group_sum(const float* x, int G, int T, int E, float* out, void* stream);
+/* y[r,:] = (accumulate ? y[r,:] : 0) + scale * x[r / x_div, :] for r < M */
+int capdec_axpy_rows(const float* x, int x_div, float scale, int M, int E, float* y, int accumulate, void* stream);
 /* out[g,:] = sum of the rows [seg_off[g], seg_off[g+1]) of x (seg_off: device, G+1 entries) */
 int capdec_group_sum_segments(const float* x, int G, const int32_t* seg_off, int E, float* out, void* stream);
 /* demb[ids[r],:] += dx[r,:]  (nn.Embedding backward, transformer.py:126 / cnnrnn_model.py:27) */
@@ -477,6 +479,12 @@ int capdec_topk_rows(const float* x, int rows, int n, int k, float* out_val, int
  * ------------------------------------------------------------------------------------------ */
 int capdec_additive_attention(const float* u, int64_t ldu, const float* pf, const float* v, const float* enc, int B, int S,
                               int A, int E, float* ctx, int64_t ldctx, float* alpha, void* stream);
+/* Backward of capdec_additive_attention for one step.  alpha [B,S] as the forward wrote it, dctx [B,E] (row stride
+ * lddctx).  du [B,A] (row stride lddu) is written; dpf [B,S,A], denc [B,S,E] and dvb [B,A] are ACCUMULATED (they collect
+ * the steps of a caption; zero them before the last step's call); the gradient of v is the column sum of dvb. */
+int capdec_additive_attention_bwd(const float* u, int64_t ldu, const float* pf, const float* v, const float* enc,
+                                  const float* alpha, const float* dctx, int64_t lddctx, int B, int S, int A, int E,
+                                  float* du, int64_t lddu, float* dpf, float* denc, float* dvb, void* stream);
 typedef struct capdec_satt_model {
     int32_t E, Hd, A, V;
     const float* emb;                          /* [V,E] */
