@@ -27,6 +27,7 @@ import torch.distributed as dist
 
 E, H, L, V, B, LEN, D = 512, 4, 2, 10000, 1024, 20, 2048
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+DIST_ON = False                    # set in main(): more than one rank (or a forced dry run of that path)
 
 
 def build_model(device):
@@ -110,7 +111,8 @@ def train_bench(device, rank, world, steps, warmup, fence, note=lambda m: None, 
     else:
         from models.vitattn_model import VITAttentionModel
         model, Dh, S = VITAttentionModel(E, V, H, Lt).to(device), 1000, 1
-    tr = CaptionTrainer(model, lr=1e-3, overlap=os.environ.get("CAPDEC_TRAIN_OVERLAP", "1") == "1", graph=use_graph)
+    tr = CaptionTrainer(model, lr=1e-3, overlap=os.environ.get("CAPDEC_TRAIN_OVERLAP", "1") == "1", graph=use_graph,
+                        exercise_collectives=DIST_ON)
     note("trainer built")
     g = torch.Generator().manual_seed(1234 + 3 + 1000 * rank)
     feats = torch.rand(Bt, Dh, generator=g).to(device)
@@ -131,7 +133,7 @@ def train_bench(device, rank, world, steps, warmup, fence, note=lambda m: None, 
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if DIST_ON and dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     # algorithmic FLOPs per sample (2 per MAC): forward = L*(16TE^2 + 4SE^2 + 4T^2E + 4TSE) + 2TEV + 2DE; x3 for training
@@ -469,7 +471,12 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ.get("CAPDEC_REHEARSAL_DUMP_S", "40")), exit=False)     # where is a stuck rank?
     device = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    # CAPDEC_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, id gather, timer all-reduce, the
+    # trainer's gradient all-reduces) even with one rank, where every collective is the identity: a dry run of the
+    # N-GPU flow on a one-GPU box, never for reported numbers
+    global DIST_ON
+    DIST_ON = world > 1 or os.environ.get("CAPDEC_BENCH_FORCE_DIST") == "1"
+    if DIST_ON:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -498,8 +505,8 @@ def main():
             enc = model.encode_features(feats).view(B, S, E)
             # one GPU: ids, lengths and flags come to the host in one copy; several: they stay on the device for the gather
             ids, lens, n_dirty = engine.tf_greedy_ids(ref, enc, LEN, 1, 2, probe=probe if use_probe else None,
-                                                      to_cpu=world == 1)
-            if world > 1:
+                                                      to_cpu=not DIST_ON)
+            if DIST_ON:
                 # batch-sharded decode: the only exchange is the final gather of the token ids
                 if rehearsal:                       # gloo gathers host tensors only
                     ids, lens = ids.cpu(), lens.cpu()
@@ -510,13 +517,13 @@ def main():
                 dist.gather(lens, list(all_len.chunk(world)) if rank == 0 else None, dst=0)
                 if rank == 0:
                     ids, lens = all_ids, all_len
-            if rank == 0 and world > 1:
+            if rank == 0 and DIST_ON:
                 ids, lens = ids.cpu(), lens.cpu()
         return ids, lens, n_dirty
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if DIST_ON:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -535,7 +542,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if DIST_ON:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -594,7 +601,7 @@ def main():
         note("train timed")
         if rank == 0:
             out["train"] = train
-        if world > 1:
+        if DIST_ON:
             # the same global batch of 512 sharded over the ranks (the other reading of "data parallel")
             watchdog = threading.Timer(args.train_budget, give_up)
             watchdog.daemon = True
@@ -615,7 +622,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     probe.close()
-    if world > 1:
+    if DIST_ON:
         dist.destroy_process_group()
 
 

@@ -86,3 +86,20 @@ def test_rccl_one_rank_group_runs_the_device_collective_branch(tmp_path):
         # same gradients up to the rounding of the weight gradients' float atomics; Adam turns a sign flip of a
         # rounding-level gradient into a step of up to lr
         assert d.max() <= 2.2 * 1e-3 * 4 and d.mean() <= 3e-6, (name, d.max(), d.mean())
+
+
+def test_bench_multi_rank_flow_runs_under_rccl_with_one_rank(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, RCCL process group, id gather, timer
+    all-reduce, trainer collectives, strong-scaling leg), dry-run with one rank: the JSON line must carry every leg."""
+    import json
+    env = dict(os.environ, CAPDEC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup",
+           "1", "--train-steps", "2", "--no-variants", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    for leg in ("train", "train_strong"):
+        assert line[leg]["value"] > 0 and "error" not in line[leg], line[leg]
+        assert line[leg]["loss_last"] < line[leg]["loss_first"]
