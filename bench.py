@@ -256,6 +256,76 @@ def cnn_rnn_variant(device, reps=50):
                     "sample": f"{n} batches of {Br} in 3 s, oracle restatement of the reference loop"}}
 
 
+def train_tokens197_variant(device, steps=6, warmup=2):
+    """Training over 197 ViT tokens of width 768 (S=197): Linear(768,E) per token, 3-layer decoder, loss, backward,
+    Adam."""
+    from capdec import autograd as AG
+    from capdec import ops
+    from capdec.trainer import CaptionTrainer
+    from models.vitattn_model import VITAttentionModel
+    g = torch.Generator().manual_seed(1234 + 2)
+    Bt, T, Lt, St, Dt = 512, 20, 3, 197, 768
+    torch.manual_seed(0)
+    m = VITAttentionModel(E, V, H, Lt).to(device).train()
+    tr = CaptionTrainer(m, lr=1e-3)
+    w_tok = (torch.randn(E, Dt, generator=g) * Dt ** -0.5).to(device)
+    b_tok = torch.zeros(E, device=device)
+    gw, gb = torch.zeros_like(w_tok), torch.zeros_like(b_tok)
+    mw, vw = torch.zeros(E * Dt + E, device=device), torch.zeros(E * Dt + E, device=device)
+    tokens = torch.randn(Bt * St, Dt, generator=g).to(device)
+    caps = torch.zeros(Bt, T + 1, dtype=torch.long)
+    for b in range(Bt):
+        n = int(torch.randint(8, 20, (1,), generator=g))       # caption body length in [8,19], as in the training leg
+        caps[b, 0] = 1
+        caps[b, 1:1 + n] = torch.randint(4, V, (n,), generator=g)
+        caps[b, 1 + n] = 2
+    caps = caps.to(device)
+    ids, tgt = caps[:, :-1].contiguous(), caps[:, 1:].contiguous()
+    ragged = AG.ragged_supported(m, St, T, Bt)
+    k = [0]
+
+    side = torch.cuda.Stream(device=device)
+
+    def tstep():
+        k[0] += 1
+        tr.flat_g.zero_()
+        gw.zero_()
+        gb.zero_()
+        AG.use_side_stream(side)           # weight-gradient contractions beside the input-gradient chain, as in CaptionTrainer
+        enc = ops.linear(tokens, w_tok, b_tok)
+        rg = ops.RaggedRows(ids, tgt, 0) if ragged else None
+        x, tape = AG.tf_forward(m, enc.view(Bt, St, E), ids, m.dropout.p, AG.draw_seed(), ragged=rg)
+        if rg is not None:
+            loss, saved = AG.vocab_loss(m, x, rg.targets_c, rows=rg.rows)
+        else:
+            loss, saved = AG.vocab_loss(m, x, tgt)
+        dx = AG.vocab_loss_bwd(m, x, saved, tr.grads)
+        denc = AG.tf_backward(m, tape, dx, tr.grads, need_denc=True)
+        ops.linear_wgrad(denc.view(Bt * St, E), tokens, out=gw)
+        ops.colsum(denc.view(Bt * St, E), gb)
+        AG.join_side_stream()
+        AG.use_side_stream(None)
+        ops.adam_step(tr.flat_p, tr.flat_g, tr.m, tr.v, 1e-3, k[0])
+        ops.adam_step(w_tok.view(-1), gw.view(-1), mw[:E * Dt], vw[:E * Dt], 1e-3, k[0])
+        ops.adam_step(b_tok, gb, mw[E * Dt:], vw[E * Dt:], 1e-3, k[0])
+        return loss
+
+    for _ in range(warmup):
+        tstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    f_fwd = Lt * (16 * T * E * E + 4 * St * E * E + 4 * T * T * E + 4 * T * St * E) + 2 * T * E * V + 2 * St * Dt * E
+    tf = 3.0 * f_fwd * Bt / dt / 1e12
+    return {"workload": f"ViT-Attn training over 197x768 tokens (S=197), B={Bt}, T={T}, L={Lt}, dropout 0.1, Adam; "
+                        "caption bodies of 8-19 tokens (27 % <PAD> tails), decoder rows ragged",
+            "value": Bt / dt, "unit": "samples/s", "ms_per_step": dt * 1e3,
+            "algorithmic_tflops": tf, "mfma_frac": tf / FP32_MFMA_PEAK_TFLOPS}
+
+
 def variants_bench(device, steps=6, warmup=2):
     """The shapes as BASELINE.json words them (secondary reading; the decoder is the same parity-pinned code, the
     per-cell / per-token projections in front of it have no counterpart in the reference's classes):
@@ -382,67 +452,7 @@ def variants_bench(device, steps=6, warmup=2):
                     f"512, V={V}: forward, CE loss, backward, Adam (no reference counterpart: parity unpinned)",
         "value": Bs / dt, "unit": "samples/s", "ms_per_step": dt * 1e3}
     del sat, grid, feats
-    # ---- training, S=197 tokens of width 768: Linear(768,E) per token, 3-layer decoder, loss, backward, Adam ----
-    Bt, T, Lt, St, Dt = 512, 20, 3, 197, 768
-    torch.manual_seed(0)
-    m = VITAttentionModel(E, V, H, Lt).to(device).train()
-    tr = CaptionTrainer(m, lr=1e-3)
-    w_tok = (torch.randn(E, Dt, generator=g) * Dt ** -0.5).to(device)
-    b_tok = torch.zeros(E, device=device)
-    gw, gb = torch.zeros_like(w_tok), torch.zeros_like(b_tok)
-    mw, vw = torch.zeros(E * Dt + E, device=device), torch.zeros(E * Dt + E, device=device)
-    tokens = torch.randn(Bt * St, Dt, generator=g).to(device)
-    caps = torch.zeros(Bt, T + 1, dtype=torch.long)
-    for b in range(Bt):
-        n = int(torch.randint(8, 20, (1,), generator=g))       # caption body length in [8,19], as in the training leg
-        caps[b, 0] = 1
-        caps[b, 1:1 + n] = torch.randint(4, V, (n,), generator=g)
-        caps[b, 1 + n] = 2
-    caps = caps.to(device)
-    ids, tgt = caps[:, :-1].contiguous(), caps[:, 1:].contiguous()
-    ragged = AG.ragged_supported(m, St, T, Bt)
-    k = [0]
-
-    side = torch.cuda.Stream(device=device)
-
-    def tstep():
-        k[0] += 1
-        tr.flat_g.zero_()
-        gw.zero_()
-        gb.zero_()
-        AG.use_side_stream(side)           # weight-gradient contractions beside the input-gradient chain, as in CaptionTrainer
-        enc = ops.linear(tokens, w_tok, b_tok)
-        rg = ops.RaggedRows(ids, tgt, 0) if ragged else None
-        x, tape = AG.tf_forward(m, enc.view(Bt, St, E), ids, m.dropout.p, AG.draw_seed(), ragged=rg)
-        if rg is not None:
-            loss, saved = AG.vocab_loss(m, x, rg.targets_c, rows=rg.rows)
-        else:
-            loss, saved = AG.vocab_loss(m, x, tgt)
-        dx = AG.vocab_loss_bwd(m, x, saved, tr.grads)
-        denc = AG.tf_backward(m, tape, dx, tr.grads, need_denc=True)
-        ops.linear_wgrad(denc.view(Bt * St, E), tokens, out=gw)
-        ops.colsum(denc.view(Bt * St, E), gb)
-        AG.join_side_stream()
-        AG.use_side_stream(None)
-        ops.adam_step(tr.flat_p, tr.flat_g, tr.m, tr.v, 1e-3, k[0])
-        ops.adam_step(w_tok.view(-1), gw.view(-1), mw[:E * Dt], vw[:E * Dt], 1e-3, k[0])
-        ops.adam_step(b_tok, gb, mw[E * Dt:], vw[E * Dt:], 1e-3, k[0])
-        return loss
-
-    for _ in range(warmup):
-        tstep()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tstep()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    f_fwd = Lt * (16 * T * E * E + 4 * St * E * E + 4 * T * T * E + 4 * T * St * E) + 2 * T * E * V + 2 * St * Dt * E
-    tf = 3.0 * f_fwd * Bt / dt / 1e12
-    out["train_tokens197"] = {"workload": f"ViT-Attn training over 197x768 tokens (S=197), B={Bt}, T={T}, L={Lt}, dropout 0.1, Adam; "
-                                          "caption bodies of 8-19 tokens (27 % <PAD> tails), decoder rows ragged",
-                              "value": Bt / dt, "unit": "samples/s", "ms_per_step": dt * 1e3,
-                              "algorithmic_tflops": tf, "mfma_frac": tf / FP32_MFMA_PEAK_TFLOPS}
+    out["train_tokens197"] = train_tokens197_variant(device, steps, warmup)
     return out
 
 

@@ -371,15 +371,20 @@ __global__ __launch_bounds__(256) void attention_short_kernel(AttnArgs a) {
 // Rows may be ragged on the query side (seq_off, ragged_q_only) exactly as in attention_short_kernel.
 constexpr int AL_KC = 32;
 
-template <int NM, int RPW>
+// Each wavefront owns the query rows i = wave + 4 * (g * RB + n), g < NG, n < RB.  The RB rows of a group are worked
+// on together: a key fragment read from LDS is dotted with all RB queries (held in registers), a value fragment is
+// scaled into all RB accumulators, so the chunk is read from LDS once per group instead of once per query row -- the
+// one-row-at-a-time form of this kernel was bound by exactly that LDS traffic (5 x the bytes at 20 query rows).
+template <int NM, int NG, int RB>
 __global__ __launch_bounds__(256) void attention_long_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int RPW = NG * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int dk = a.dk, LD = dk + 16, Tk = a.Tk;
     float* Qs = lds;                       // [a.Tq][LD]
     float* Ks = Qs + a.Tq * LD;            // [AL_KC][LD]
     float* Vs = Ks + AL_KC * LD;           // [AL_KC][LD]
-    float* sc = Vs + AL_KC * LD + wave * AL_KC;     // this wavefront's scores of the chunk
+    float* sc = Vs + AL_KC * LD + wave * (RB * AL_KC);     // this wavefront's exp-scores of the chunk, [RB][AL_KC]
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
     const int nv = dk / 4;
     int Tq = a.Tq;
@@ -390,14 +395,23 @@ __global__ __launch_bounds__(256) void attention_long_kernel(AttnArgs a) {
     }
     const float* kb = a.k + (int64_t)b * a.sk + (int64_t)h * dk;
     const float* vb = a.v + (int64_t)b * a.sv + (int64_t)h * dk;
-    for (int idx = threadIdx.x; idx < Tq * nv; idx += 256) {
+    for (int idx = threadIdx.x; idx < a.Tq * nv; idx += 256) {
         const int r = idx / nv, c = idx - r * nv;
+        // rows past this sample's end are staged as zeros: their results are never stored
         *reinterpret_cast<f32x4*>(&Qs[r * LD + 4 * c]) =
-            *reinterpret_cast<const f32x4*>(a.q + (q0 + r) * a.ldq + (int64_t)h * dk + 4 * c);
+            r < Tq ? *reinterpret_cast<const f32x4*>(a.q + (q0 + r) * a.ldq + (int64_t)h * dk + 4 * c)
+                   : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float scale = sqrtf((float)dk);
-    const int part = lane & 3, kl = lane >> 2;
-    const int lpv = dk / 4, grp = lane / lpv, dl = lane - grp * lpv, ngrp = 64 / lpv;
+    const float inv_scale = 1.0f / sqrtf((float)dk);
+    // score sweep: LPK lanes share a key (each holds NQ float4 of the query rows and of the key), 64 / LPK keys per
+    // sweep.  Eight lanes per key halve the query registers of the four-lane form, which is what lets two
+    // workgroups share a CU: with one, nothing hides the chunk loads.
+    constexpr int LPK = NM >= 2 ? 8 : 4, NQ = 4 * NM / LPK, KPS = 64 / LPK, NSW = AL_KC / KPS;
+    const int part = lane & (LPK - 1), kl = lane / LPK;
+    constexpr int LPV = 4 * NM;            // lanes per key in the value sweep (one float4 of the head each)
+    constexpr int NGRP = 64 / LPV;         // key groups of that sweep
+    constexpr int KPG = AL_KC / NGRP;      // consecutive keys per group
+    const int grp = lane / LPV, dl = lane - grp * LPV;
     float mrow[RPW], lrow[RPW];
     f32x4 acc[RPW];
 #pragma unroll
@@ -406,58 +420,111 @@ __global__ __launch_bounds__(256) void attention_long_kernel(AttnArgs a) {
         lrow[n] = 0.f;
         acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    f32x4 qreg[RB][NQ];
+    if (NG == 1) {                         // one group: its queries stay in registers across all chunks
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < RB; ++n)
+#pragma unroll
+            for (int m = 0; m < NQ; ++m)
+                qreg[n][m] = *reinterpret_cast<const f32x4*>(Qs + min(wave + 4 * n, a.Tq - 1) * LD + 4 * part +
+                                                             4 * LPK * m);
+    }
     for (int c0 = 0; c0 < Tk; c0 += AL_KC) {
         const int nk = min(AL_KC, Tk - c0);
         __syncthreads();                   // the previous chunk is consumed (and the queries are staged)
-        for (int idx = threadIdx.x; idx < nk * nv; idx += 256) {
+        for (int idx = threadIdx.x; idx < AL_KC * nv; idx += 256) {
             const int r = idx / nv, c = idx - r * nv;
+            const int rr = min(r, nk - 1);                 // rows past the end repeat the last key: masked below
             *reinterpret_cast<f32x4*>(&Ks[r * LD + 4 * c]) =
-                *reinterpret_cast<const f32x4*>(kb + (int64_t)(c0 + r) * a.ldk + 4 * c);
+                *reinterpret_cast<const f32x4*>(kb + (int64_t)(c0 + rr) * a.ldk + 4 * c);
             *reinterpret_cast<f32x4*>(&Vs[r * LD + 4 * c]) =
-                *reinterpret_cast<const f32x4*>(vb + (int64_t)(c0 + r) * a.ldv + 4 * c);
+                *reinterpret_cast<const f32x4*>(vb + (int64_t)(c0 + rr) * a.ldv + 4 * c);
         }
         __syncthreads();
 #pragma unroll
-        for (int n = 0; n < RPW; ++n) {
-            const int i = wave + 4 * n;
-            if (i >= Tq) break;
-            f32x4 qreg[NM];
+        for (int g = 0; g < NG; ++g) {
+            if (wave + 4 * g * RB >= Tq) break;
+            if (NG > 1) {
 #pragma unroll
-            for (int m = 0; m < NM; ++m) qreg[m] = *reinterpret_cast<const f32x4*>(Qs + i * LD + 4 * part + 16 * m);
-            float cm = -INFINITY;
-            for (int j0 = 0; j0 < nk; j0 += 16) {
-                const int j = j0 + kl;
-                float d = 0.f;
-                if (j < nk) {
-                    const float* kp = Ks + j * LD + 4 * part;
+                for (int n = 0; n < RB; ++n)
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) {
-                        const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 16 * m);
-                        d += qreg[m][0] * kk[0] + qreg[m][1] * kk[1] + qreg[m][2] * kk[2] + qreg[m][3] * kk[3];
+                    for (int m = 0; m < NQ; ++m)
+                        qreg[n][m] = *reinterpret_cast<const f32x4*>(Qs + min(wave + 4 * (g * RB + n), a.Tq - 1) * LD +
+                                                                     4 * part + 4 * LPK * m);
+            }
+            // scores of the chunk's 32 keys against the RB queries: KPS keys x LPK parts per sweep
+            float d[NSW][RB];
+#pragma unroll
+            for (int sw = 0; sw < NSW; ++sw) {
+                const int j = KPS * sw + kl;
+                f32x4 kk[NQ];
+#pragma unroll
+                for (int m = 0; m < NQ; ++m)
+                    kk[m] = *reinterpret_cast<const f32x4*>(Ks + j * LD + 4 * part + 4 * LPK * m);
+#pragma unroll
+                for (int n = 0; n < RB; ++n) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int m = 0; m < NQ; ++m)
+                        t += qreg[n][m][0] * kk[m][0] + qreg[n][m][1] * kk[m][1] + qreg[n][m][2] * kk[m][2] +
+                             qreg[n][m][3] * kk[m][3];
+#pragma unroll
+                    for (int o = 1; o < LPK; o <<= 1) t += __shfl_xor(t, o, 64);
+                    d[sw][n] = j < nk ? t * inv_scale : -INFINITY;
+                }
+            }
+            float alpha[RB];
+#pragma unroll
+            for (int n = 0; n < RB; ++n) {
+                const int r = g * RB + n;
+                float cm = d[0][n];
+#pragma unroll
+                for (int sw = 1; sw < NSW; ++sw) cm = fmaxf(cm, d[sw][n]);
+#pragma unroll
+                for (int o = LPK; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
+                const float mnew = fmaxf(mrow[r], cm);
+                alpha[n] = expf(mrow[r] - mnew);               // 0 on the first chunk (exp(-inf))
+                float ps = 0.f;
+#pragma unroll
+                for (int sw = 0; sw < NSW; ++sw) {
+                    const float e = expf(d[sw][n] - mnew);      // 0 for the keys past the end
+                    if (part == 0) sc[n * AL_KC + KPS * sw + kl] = e;
+                    ps += e;
+                }
+                // every lane of a key's LPK holds the same values: the wave total counts each key LPK times
+#pragma unroll
+                for (int o = LPK; o < 64; o <<= 1) ps += __shfl_xor(ps, o, 64);
+                lrow[r] = lrow[r] * alpha[n] + ps;
+                mrow[r] = mnew;
+            }
+            // LDS serves one wavefront's accesses in order: the exp-scores above are visible to its other lanes
+            f32x4 add[RB];
+#pragma unroll
+            for (int n = 0; n < RB; ++n) add[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (KPG % 4 == 0) {
+#pragma unroll
+                for (int jq = 0; jq < KPG / 4; ++jq) {
+                    const int j4 = grp * KPG + 4 * jq;
+                    f32x4 pf[RB];
+#pragma unroll
+                    for (int n = 0; n < RB; ++n) pf[n] = *reinterpret_cast<const f32x4*>(sc + n * AL_KC + j4);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + (j4 + jj) * LD + 4 * dl);
+#pragma unroll
+                        for (int n = 0; n < RB; ++n) add[n] += vv * pf[n][jj];
                     }
                 }
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                d /= scale;
-                if (j < nk) {
-                    cm = fmaxf(cm, d);
-                    if (part == 0) sc[j] = d;
+            } else {
+                for (int j = grp * KPG; j < (grp + 1) * KPG; ++j) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + j * LD + 4 * dl);
+#pragma unroll
+                    for (int n = 0; n < RB; ++n) add[n] += vv * sc[n * AL_KC + j];
                 }
             }
-            // LDS serves one wavefront's accesses in order: the scores above are visible to its other lanes
-            const float mnew = fmaxf(mrow[n], wave_max(cm));
-            const float alpha = expf(mrow[n] - mnew);          // 0 on the first chunk (exp(-inf))
-            float ps = 0.f;
-            for (int j = lane; j < nk; j += 64) {
-                const float e = expf(sc[j] - mnew);
-                sc[j] = e;
-                ps += e;
-            }
-            lrow[n] = lrow[n] * alpha + wave_sum(ps);
-            mrow[n] = mnew;
-            f32x4 add = {0.f, 0.f, 0.f, 0.f};
-            for (int j = grp; j < nk; j += ngrp) add += *reinterpret_cast<const f32x4*>(Vs + j * LD + 4 * dl) * sc[j];
-            acc[n] = acc[n] * alpha + add;
+#pragma unroll
+            for (int n = 0; n < RB; ++n) acc[g * RB + n] = acc[g * RB + n] * alpha[n] + add[n];
         }
     }
 #pragma unroll
@@ -465,7 +532,7 @@ __global__ __launch_bounds__(256) void attention_long_kernel(AttnArgs a) {
         const int i = wave + 4 * n;
         if (i >= Tq) break;
         f32x4 o = acc[n];
-        for (int s = lpv; s < 64; s <<= 1) {
+        for (int s = LPV; s < 64; s <<= 1) {
             o[0] += __shfl_xor(o[0], s, 64);
             o[1] += __shfl_xor(o[1], s, 64);
             o[2] += __shfl_xor(o[2], s, 64);
@@ -605,31 +672,35 @@ static int launch_attention_long(const AttnArgs& a, hipStream_t s, bool* used) {
     *used = false;
     const int Tq = a.Tq, dk = a.dk;
     if (a.causal || a.ids || a.row_map || Tq < 4 || Tq > 64 || a.Tk <= 64 || g_attention_no_long) return 0;
-    const size_t smem = ((size_t)(Tq + 2 * AL_KC) * (dk + 16) + 4 * AL_KC) * sizeof(float);
+    // rows per wavefront = ceil(Tq / 4), worked on in NG groups of RB rows
+    const int rpw = (Tq + 3) / 4;
+    const int rb = (rpw == 5 || rpw == 9 || rpw == 10) ? 5 : 4;
+    const size_t smem = ((size_t)(Tq + 2 * AL_KC) * (dk + 16) + 4 * rb * AL_KC) * sizeof(float);
     if (smem > 144 * 1024) return 0;
+#define CAPDEC_FORMS(NM_, X)  X(NM_, 1, 4) X(NM_, 1, 5) X(NM_, 2, 4) X(NM_, 2, 5) X(NM_, 4, 4)
     static const bool ready = [] {
         bool ok = true;
-#define CAPDEC_CALL(NM_)                                                                                              \
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<NM_, 4>),                      \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess &&           \
-         hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<NM_, 8>),                            \
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess &&                 \
-         hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<NM_, 16>),                           \
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess
-        CAPDEC_CALL(1); CAPDEC_CALL(2); CAPDEC_CALL(4); CAPDEC_CALL(8); CAPDEC_CALL(16);
-#undef CAPDEC_CALL
+#define CAPDEC_SET(NM_, NG_, RB_)                                                                                      \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<NM_, NG_, RB_>),                \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess;
+        CAPDEC_FORMS(1, CAPDEC_SET) CAPDEC_FORMS(2, CAPDEC_SET) CAPDEC_FORMS(4, CAPDEC_SET) CAPDEC_FORMS(8, CAPDEC_SET)
+        CAPDEC_FORMS(16, CAPDEC_SET)
+#undef CAPDEC_SET
         return ok;
     }();
     if (!ready) return CAPDEC_EINVAL;
     const dim3 grid((unsigned)(a.B * a.H));
 #define CAPDEC_CALL(NM_)                                                                                       \
     do {                                                                                                       \
-        if (Tq <= 16) hipLaunchKernelGGL((attention_long_kernel<NM_, 4>), grid, dim3(256), smem, s, a);        \
-        else if (Tq <= 32) hipLaunchKernelGGL((attention_long_kernel<NM_, 8>), grid, dim3(256), smem, s, a);   \
-        else hipLaunchKernelGGL((attention_long_kernel<NM_, 16>), grid, dim3(256), smem, s, a);                \
+        if (rpw <= 4) hipLaunchKernelGGL((attention_long_kernel<NM_, 1, 4>), grid, dim3(256), smem, s, a);     \
+        else if (rpw == 5) hipLaunchKernelGGL((attention_long_kernel<NM_, 1, 5>), grid, dim3(256), smem, s, a); \
+        else if (rpw <= 8) hipLaunchKernelGGL((attention_long_kernel<NM_, 2, 4>), grid, dim3(256), smem, s, a); \
+        else if (rpw <= 10) hipLaunchKernelGGL((attention_long_kernel<NM_, 2, 5>), grid, dim3(256), smem, s, a); \
+        else hipLaunchKernelGGL((attention_long_kernel<NM_, 4, 4>), grid, dim3(256), smem, s, a);              \
     } while (0)
     CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
 #undef CAPDEC_CALL
+#undef CAPDEC_FORMS
     CAPDEC_LAUNCH_CHECK();
     *used = true;
     return 0;
