@@ -29,6 +29,13 @@ class GemmGroup(Structure):
                 ("ldrj", c_int64), ("I", c_int32), ("J", c_int32), ("c_rows", c_void_p)]
 
 
+class BgemmDesc(Structure):
+    _fields_ = [("P", c_void_p), ("Q", c_void_p), ("C", c_void_p), ("P2", c_void_p), ("Q2", c_void_p),
+                ("ldp", c_int64), ("ldq", c_int64), ("ldc", c_int64), ("dense_stride", c_int64), ("seg_off", c_void_p),
+                ("mult", c_int32), ("seg", c_int32), ("B", c_int32), ("I", c_int32), ("J", c_int32), ("K", c_int32),
+                ("scale", c_float), ("accumulate", c_int32)]
+
+
 class GemmExtra(Structure):
     _fields_ = [("mask", c_void_p), ("ldm", c_int64), ("lse", c_void_p), ("tgt", c_void_p), ("gscale", c_void_p),
                 ("ignore_index", c_int64), ("rows_dev", c_void_p), ("k_dev", c_void_p), ("splitk_ws", c_void_p),
@@ -88,6 +95,9 @@ _SIGNATURES = {
     "capdec_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P, _P]),
     "capdec_colsum": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
     "capdec_colsum_rows": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P]),
+    "capdec_bgemm": (c_int, [POINTER(BgemmDesc), c_int, _P]),
+    "capdec_softmax_rows": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "capdec_softmax_rows_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_float, _P, c_int, c_int, _P]),
     "capdec_softmax_nll_grad": (c_int, [_P, c_int64, _P, c_int, c_int, c_int64, _P, _P, _P, _P]),
     "capdec_softmax_nll_grad_rows": (c_int, [_P, c_int64, _P, c_int, c_int, c_int64, _P, _P, _P, _P, _P]),
     "capdec_compact_targets": (c_int, [_P, c_int, c_int64, _P, _P, _P, _P, _P]),

@@ -99,7 +99,103 @@ def ragged_supported(dec, S, T, B=1):
             ((T + 64) * (dk + 16) + 128) * 4 <= 144 * 1024)
 
 
-def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, seed_dev=None):
+def cross_absorbed(S, T, E, H):
+    """Whether the cross-attention sub-layer of a teacher-forced pass contracts the memory against the H*T query rows
+    of a sample (key / value projections folded onto the query side) instead of projecting its S rows: multiply-adds
+    per sample 2*T*(H*S + E)*E against 2*S*E*E + 2*T*S*E, taken when it is at most half."""
+    dk = E // H
+    return S > 64 and E % 4 == 0 and dk % 4 == 0 and 2 * T * (H * S + E) <= S * E + T * S
+
+
+def _heads(t, H, width):
+    """The H column blocks of ``width`` columns of a 2-D tensor, as views."""
+    return [t[:, h * width:(h + 1) * width] for h in range(H)]
+
+
+def _on_side(fn, keep):
+    """Run ``fn`` on the side stream when there is one (after everything enqueued so far on the current stream), else
+    here.  ``keep``: tensors read by it, whose memory must outlive the side stream's work."""
+    side = _side()
+    if side is None:
+        fn()
+        return
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    for tn in keep:
+        tn.record_stream(side)
+
+
+def _cross_absorbed_fwd(t, c, ca, rows):
+    """scores = (q_h W_k,h) mem^T / sqrt(dk), probabilities, context = P mem, out_h = context W_v,h^T + b_v,h.
+    Row (r, h) of the per-head tensors is row r*H + h.  Returns the sub-layer's attention output [M, E]."""
+    B, S, T, E, H = t.B, t.S, t.T, t.E, t.H
+    dk, M = E // H, c.q2.shape[0]
+    rg = t.ragged
+    seg_off = None if rg is None else rg.seq_off
+    dev = c.q2.device
+    c.qp = torch.empty((M * H, E), device=dev, dtype=torch.float32)
+    qp_heads = _heads(c.qp.view(M, H * E), H, E)
+    wk = ca.W_k.weight
+    ops.gemm_layout_groups([dict(P=q, Q=wk[h * dk:(h + 1) * dk], C=qp_heads[h])
+                            for h, q in enumerate(_heads(c.q2, H, dk))], "nn", rows_dev=rows)
+    c.p2 = torch.empty((M * H, (S + 31) // 32 * 32), device=dev, dtype=torch.float32)
+    ops.bgemm("nt", c.qp, t.enc, c.p2, B, T, H, seg_off=seg_off, scale=dk ** -0.5)
+    ops.softmax_rows_(c.p2, S, live=seg_off, live_idx=B, mult=H)
+    c.c2 = torch.zeros((M * H, E), device=dev, dtype=torch.float32)      # rows of no sample stay zero
+    ops.bgemm("nn", c.p2, t.enc, c.c2, B, T, H, seg_off=seg_off)
+    ao2 = torch.empty((M, E), device=dev, dtype=torch.float32)
+    wv, bv = ca.W_v.weight, ca.W_v.bias
+    ops.gemm_layout_groups([dict(P=cc, Q=wv[h * dk:(h + 1) * dk], C=o, bias_j=bv[h * dk:(h + 1) * dk])
+                            for h, (cc, o) in enumerate(zip(_heads(c.c2.view(M, H * E), H, E), _heads(ao2, H, dk)))],
+                           "nt", rows_dev=rows)
+    return ao2
+
+
+def _cross_absorbed_bwd(t, c, ca, pre, d_ao2, grads, rows, denc, first=False):
+    """Backward of ``_cross_absorbed_fwd``: fills the W_k / W_v gradients, adds the memory's gradient onto ``denc``
+    (when not None; ``first``: stores it instead, the buffer holds nothing yet), returns dq2 [M, E]."""
+    B, S, T, E, H = t.B, t.S, t.T, t.E, t.H
+    dk, M = E // H, c.q2.shape[0]
+    rg = t.ragged
+    seg_off = None if rg is None else rg.seq_off
+    dev = d_ao2.device
+    wk, wv = ca.W_k.weight, ca.W_v.weight
+    g_wk, g_wv = _new(grads, pre + "cross_attn.W_k.weight", wk), _new(grads, pre + "cross_attn.W_v.weight", wv)
+    _new(grads, pre + "cross_attn.W_k.bias", ca.W_k.bias)       # exactly zero: b_k drops out of the softmax
+    g_bv = _new(grads, pre + "cross_attn.W_v.bias", ca.W_v.bias)
+    dao_heads = _heads(d_ao2, H, dk)
+    c2_heads = _heads(c.c2.view(M, H * E), H, E)
+
+    def wv_grads():
+        ops.gemm_layout_groups([dict(P=dao_heads[h], Q=c2_heads[h], C=g_wv[h * dk:(h + 1) * dk]) for h in range(H)],
+                               "tn", k_dev=rows)
+        ops.colsum(d_ao2, g_bv, rows_dev=rows)                   # the probabilities of a row sum to one
+
+    _on_side(wv_grads, (d_ao2, c.c2))
+    dc = torch.empty((M * H, E), device=dev, dtype=torch.float32)
+    dc_heads = _heads(dc.view(M, H * E), H, E)
+    ops.gemm_layout_groups([dict(P=dao_heads[h], Q=wv[h * dk:(h + 1) * dk], C=dc_heads[h]) for h in range(H)], "nn",
+                           rows_dev=rows)
+    dp = torch.empty_like(c.p2)
+    ops.bgemm("nt", dc, t.enc, dp, B, T, H, seg_off=seg_off)
+    ops.softmax_rows_bwd_(c.p2, dp, S, scale=dk ** -0.5, live=seg_off, live_idx=B, mult=H)
+    dqp = torch.zeros((M * H, E), device=dev, dtype=torch.float32)   # rows of no sample must not reach the W_k gradient
+    ops.bgemm("nn", dp, t.enc, dqp, B, T, H, seg_off=seg_off)
+    if denc is not None:
+        # d mem = P^T d context + dS^T (q W_k): one pass over the memory's gradient for both products
+        ops.bgemm("tn", c.p2, dc, denc, B, T, H, seg_off=seg_off, P2=dp, Q2=c.qp, accumulate=not first)
+    dqp_heads = _heads(dqp.view(M, H * E), H, E)
+    q2_heads = _heads(c.q2, H, dk)
+    _on_side(lambda: ops.gemm_layout_groups([dict(P=q2_heads[h], Q=dqp_heads[h], C=g_wk[h * dk:(h + 1) * dk])
+                                             for h in range(H)], "tn", k_dev=rows), (c.q2, dqp))
+    dq2 = torch.empty((M, E), device=dev, dtype=torch.float32)
+    ops.gemm_layout_groups([dict(P=dqp_heads[h], Q=wk[h * dk:(h + 1) * dk], C=o)
+                            for h, o in enumerate(_heads(dq2, H, dk))], "nt", rows_dev=rows)
+    return dq2
+
+
+def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, seed_dev=None, absorb_cross=None):
     """Teacher-forced decoder stack (reference transformer.py:125-132) keeping what the backward needs.
     enc [B,S,E] fp32, ids [B,T] int64.  Returns (x [B*T,E] post-LN output of the last layer, tape).
 
@@ -107,13 +203,16 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, se
     rows only (the memories, and with them the K/V projections of the cross-attention, stay dense).  Every [B*T,E] tensor is then indexed by slot, the first ``ragged.rows[0]`` rows exist, and the caller
     takes the loss against ``ragged.targets_c`` with that row limit.  The dropout masks are drawn per slot.
     seed_dev (int64 device tensor, optional): its first element is added to ``seed`` by every kernel that draws a mask
-    (a step captured in a HIP graph keeps ``seed`` for ever; the device value changes from replay to replay)."""
+    (a step captured in a HIP graph keeps ``seed`` for ever; the device value changes from replay to replay).
+    absorb_cross: None = decide by ``cross_absorbed`` (long memories, few query rows); True / False force the form of
+    the cross-attention sub-layer (the two forms differ only in the order of the floating-point sums)."""
     B, S, E = enc.shape
     T = ids.shape[1]
     M, H = B * T, dec.num_heads
     t = Tape()
     t.B, t.S, t.T, t.E, t.H, t.p, t.seed, t.seed_dev = B, S, T, E, H, p, seed, seed_dev
     t.shortcut = S == 1 and single_row_shortcut
+    t.absorbed = (not t.shortcut) and absorb_cross is not False and (absorb_cross or cross_absorbed(S, T, E, H))
     t.ids = ids.contiguous()
     t.ids32 = t.ids.to(torch.int32)
     t.enc = enc.reshape(B * S, E)
@@ -178,14 +277,17 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, se
                                                              seed_dev=seed_dev)
         else:
             c.q2 = ops.linear(c.x1, ca.W_q.weight, ca.W_q.bias, rows_dev=rows)
-            kv2 = torch.empty((2, B * S, E), device=x.device, dtype=torch.float32)
-            ops.gemm_groups([dict(P=t.enc, Q=ca.W_k.weight, C=kv2[0], bias_j=ca.W_k.bias),
-                             dict(P=t.enc, Q=ca.W_v.weight, C=kv2[1], bias_j=ca.W_v.bias)], E)
-            c.kv2 = kv2
-            if ragged is not None:
-                c.ao2, c.lse2 = ops.cross_attention_ragged(c.q2, kv2[0], kv2[1], ragged, H, S, want_lse=True)
+            if t.absorbed:
+                c.ao2 = _cross_absorbed_fwd(t, c, ca, rows)
             else:
-                c.ao2, c.lse2 = ops.attention(c.q2, kv2[0], kv2[1], B, H, T, S, want_lse=True)
+                kv2 = torch.empty((2, B * S, E), device=x.device, dtype=torch.float32)
+                ops.gemm_groups([dict(P=t.enc, Q=ca.W_k.weight, C=kv2[0], bias_j=ca.W_k.bias),
+                                 dict(P=t.enc, Q=ca.W_v.weight, C=kv2[1], bias_j=ca.W_v.bias)], E)
+                c.kv2 = kv2
+                if ragged is not None:
+                    c.ao2, c.lse2 = ops.cross_attention_ragged(c.q2, kv2[0], kv2[1], ragged, H, S, want_lse=True)
+                else:
+                    c.ao2, c.lse2 = ops.attention(c.q2, kv2[0], kv2[1], B, H, T, S, want_lse=True)
             a2 = ops.linear(c.ao2, ca.W_o.weight, ca.W_o.bias, rows_dev=rows)
             c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(a2, c.x1, ly.norm2.weight, ly.norm2.bias, p, sd + _SITE,
                                                              rows_dev=rows, seed_dev=seed_dev)
@@ -205,7 +307,10 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
     rg = t.ragged
     rows = None if rg is None else rg.rows
     side_used = False
-    denc = torch.zeros((B * S, E), device=dx.device, dtype=torch.float32) if need_denc else None
+    denc = None
+    if need_denc:
+        # the folded cross-attention's first contribution overwrites the buffer: no zero fill of B*S*E floats
+        denc = (torch.empty if t.absorbed else torch.zeros)((B * S, E), device=dx.device, dtype=torch.float32)
     for l in range(len(t.layers) - 1, -1, -1):
         ly, c = dec.decoder_layers[l], t.layers[l]
         pre = f"decoder_layers.{l}."
@@ -252,13 +357,18 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
                 _new(grads, pre + "cross_attn." + n, prm)                              # exactly zero
         else:
             d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2, bias_done=True, rows=rows)
-            if rg is not None:
-                dq2, dk2, dv2 = ops.cross_attention_bwd_ragged(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, rg, H, S, out=c.ao2)
+            if t.absorbed:
+                dq2 = _cross_absorbed_bwd(t, c, ca, pre, d_ao2, grads, rows, denc, first=l == len(t.layers) - 1)
+                _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1, rows=rows)
             else:
-                dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S, out=c.ao2)
-            _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1, rows=rows)
-            _lin_bwd(grads, pre + "cross_attn.W_k", ca.W_k, dk2, t.enc, need_dx=need_denc, accum=denc)
-            _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, dv2, t.enc, need_dx=need_denc, accum=denc)
+                if rg is not None:
+                    dq2, dk2, dv2 = ops.cross_attention_bwd_ragged(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, rg, H, S,
+                                                                   out=c.ao2)
+                else:
+                    dq2, dk2, dv2 = ops.attention_bwd(c.q2, c.kv2[0], c.kv2[1], d_ao2, c.lse2, B, H, T, S, out=c.ao2)
+                _lin_bwd(grads, pre + "cross_attn.W_q", ca.W_q, dq2, c.x1, accum=d_x1, rows=rows)
+                _lin_bwd(grads, pre + "cross_attn.W_k", ca.W_k, dk2, t.enc, need_dx=need_denc, accum=denc)
+                _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, dv2, t.enc, need_dx=need_denc, accum=denc)
         # x1 = LN1(x + drop(a)),  a = attn(x Wq, x Wk, x Wv; causal, PAD rows) Wo
         d_x, d_a = ops.layernorm_bwd(d_x1, c.s1, c.m1, c.r1, ly.norm1.weight, p, sd,
                                      _new(grads, pre + "norm1.weight", ly.norm1.weight),

@@ -325,6 +325,100 @@ def gemm_raw(P, Q, C, I, J, K, ldp, ldq, flags=0, bias_j=None, R=None, mask=None
     return C
 
 
+def gemm_layout_groups(groups, layout, rows_dev=None, k_dev=None):
+    """Up to four contractions of one layout in one launch; each group is a dict of 2-D row-contiguous views P, Q, C
+    (+ optional bias_j):
+      "nt": C[I,J] = P[I,K] Q[J,K]^T + bias_j       "nn": C[I,J] = P[I,K] Q[K,J]
+      "tn": C[I,J] += P[K,I]^T Q[K,J]   (split over workgroups, summed with float atomics: C is accumulated into)
+    rows_dev limits the output rows (nt, nn), k_dev the contraction length (tn): int32 device scalars."""
+    lib = _lib.load()
+    n = len(groups)
+    arr = (GemmGroup * n)()
+    K = None
+    for g, d in zip(arr, groups):
+        P, Q, C = _chk(d["P"], name="P"), _chk(d["Q"], name="Q"), _chk(d["C"], name="C")
+        if layout == "nt":
+            (I, k), (J, k2) = P.shape, Q.shape
+        elif layout == "nn":
+            (I, k), (k2, J) = P.shape, Q.shape
+        elif layout == "tn":
+            (k, I), (k2, J) = P.shape, Q.shape
+        else:
+            raise RuntimeError(f"capdec gemm: unknown layout {layout!r}")
+        if k != k2 or tuple(C.shape) != (I, J) or (K is not None and k != K):
+            raise RuntimeError(f"capdec gemm ({layout}): shapes {tuple(P.shape)} {tuple(Q.shape)} -> {tuple(C.shape)}")
+        K = k
+        g.P, g.Q, g.C = P.data_ptr(), Q.data_ptr(), C.data_ptr()
+        g.ldp, g.ldq, g.ldci, g.ldcj, g.I, g.J = _row_stride(P, "P"), _row_stride(Q, "Q"), _row_stride(C, "C"), 1, I, J
+        b = d.get("bias_j")
+        if b is not None:
+            if layout == "tn" or _chk(b, name="bias_j").numel() != J or not b.is_contiguous():
+                raise RuntimeError("capdec gemm: bias_j must hold J contiguous values (nt / nn only)")
+            g.bias_j = b.data_ptr()
+    flags = {"nt": 0, "nn": _lib.GEMM_TQ, "tn": _lib.GEMM_TP | _lib.GEMM_TQ | _lib.GEMM_ATOMIC}[layout]
+    ex = _lib.GemmExtra()
+    if rows_dev is not None:
+        ex.rows_dev = _chk(rows_dev, torch.int32, "rows_dev").data_ptr()
+    if k_dev is not None:
+        ex.k_dev = _chk(k_dev, torch.int32, "k_dev").data_ptr()
+    _lib.check(lib.capdec_gemm_ex(arr, n, K, flags, byref(ex), _stream()), "capdec_gemm_ex")
+
+
+def bgemm(form, P, Q, C, B, seg, mult, seg_off=None, scale=1.0, P2=None, Q2=None, accumulate=False):
+    """Per-sample contractions over a ragged batch (capdec_bgemm in capdec.h).  form "nt" / "nn": P, C hold the
+    samples' rows ([rows, K] / [rows, J]), Q is [B*J, K] / [B*K, J]; form "tn": P, Q hold the rows ([rows, I>=..],
+    [rows, J]) and C is [B*I, J].  The per-sample sizes come from the dense operand's shape."""
+    lib = _lib.load()
+    d = _lib.BgemmDesc()
+    for t, nm in ((P, "P"), (Q, "Q"), (C, "C")):
+        _chk(t, name=nm)
+    d.P, d.Q, d.C = P.data_ptr(), Q.data_ptr(), C.data_ptr()
+    d.ldp, d.ldq, d.ldc = _row_stride(P, "P"), _row_stride(Q, "Q"), _row_stride(C, "C")
+    d.B, d.seg, d.mult, d.scale, d.accumulate = B, seg, mult, scale, 1 if accumulate else 0
+    d.seg_off = None if seg_off is None else _chk(seg_off, torch.int32, "seg_off").data_ptr()
+    if form == "nt":
+        d.J, d.K, d.I = Q.shape[0] // B, Q.shape[1], 1
+        d.dense_stride = d.J * d.ldq
+        code = 0
+    elif form == "nn":
+        d.K, d.J, d.I = Q.shape[0] // B, Q.shape[1], 1
+        d.dense_stride = d.K * d.ldq
+        code = 1
+    elif form == "tn":
+        d.I, d.J, d.K = C.shape[0] // B, C.shape[1], 1
+        d.dense_stride = d.I * d.ldc
+        code = 2
+        if P2 is not None:
+            if _row_stride(P2, "P2") != d.ldp or _row_stride(Q2, "Q2") != d.ldq:
+                raise RuntimeError("capdec bgemm: P2 / Q2 must have the row strides of P / Q")
+            d.P2, d.Q2 = _chk(P2, name="P2").data_ptr(), _chk(Q2, name="Q2").data_ptr()
+    else:
+        raise RuntimeError(f"capdec bgemm: unknown form {form!r}")
+    _lib.check(lib.capdec_bgemm(byref(d), code, _stream()), "capdec_bgemm")
+    return C
+
+
+def softmax_rows_(s, cols, live=None, live_idx=0, mult=1):
+    """In place: every row of s [rows, ld] becomes softmax(row[:cols]), zeros from there to the row's end.  live: int32
+    device array; only the first live[live_idx]*mult rows are touched."""
+    lib = _lib.load()
+    rows, ld = s.shape[0], _row_stride(s, "s")
+    _lib.check(lib.capdec_softmax_rows(_chk(s).data_ptr(), ld, rows, cols, s.shape[1], _ptr(live), live_idx, mult,
+                                       _stream()), "capdec_softmax_rows")
+    return s
+
+
+def softmax_rows_bwd_(p, dp, cols, scale=1.0, live=None, live_idx=0, mult=1):
+    """In place on dp: dp <- p * (dp - sum_j p_j dp_j) * scale over the first ``cols`` columns, zeros after them."""
+    lib = _lib.load()
+    rows, ld = p.shape[0], _row_stride(p, "p")
+    if dp.shape != p.shape or _row_stride(dp, "dp") != ld:
+        raise RuntimeError("capdec softmax_rows_bwd_: p and dp must have the same shape and row stride")
+    _lib.check(lib.capdec_softmax_rows_bwd(_chk(p).data_ptr(), _chk(dp).data_ptr(), ld, rows, cols, p.shape[1], scale,
+                                           _ptr(live), live_idx, mult, _stream()), "capdec_softmax_rows_bwd")
+    return dp
+
+
 def linear_dgrad(dy, W, mask=None, accum=None, rows_dev=None):
     """dX = dY W  (dY [M,N], W [N,K]); zeroed where mask <= 0; added onto ``accum`` in place when given."""
     M, N = dy.shape

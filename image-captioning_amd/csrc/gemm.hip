@@ -189,7 +189,9 @@ constexpr int lds_floats() {
 template <int WM, int WI, int WJ, int BK, bool VEC, bool TP = false, bool TQ = false, int KG = 1>
 __device__ __forceinline__ void mainloop(const float* __restrict__ P, const float* __restrict__ Q, int64_t ldp,
                                          int64_t ldq, int I, int J, int K, int i0, int j0, int kt0, int kt1,
-                                         float* lds, f32x16 (&acc)[WI][WJ]) {
+                                         float* lds, f32x16 (&acc)[WI][WJ], bool keep_acc = false, int KQ = -1) {
+    // keep_acc: add onto the caller's accumulators instead of starting from zero (a second product into the same tile)
+    // KQ: contraction length of Q when it differs from P's (P padded with zero columns up to a multiple of four)
     constexpr int GT = 128 * WM;                  // threads per k-group
     using OpP = Operand<32 * WM * WI, BK, VEC, TP, GT>;
     using OpQ = Operand<64 * WJ, BK, VEC, TQ, GT>;
@@ -201,14 +203,16 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ P, const floa
     const int r = lane & 31, h = lane >> 5;
     float* glds = lds + kg * GROUP_LDS;
     const OpP op{P, ldp, I, K, i0, glds, tid};
-    const OpQ oq{Q, ldq, J, K, j0, glds + 2 * OpP::BUF, tid};
+    const OpQ oq{Q, ldq, J, KQ >= 0 ? KQ : K, j0, glds + 2 * OpP::BUF, tid};
 
+    if (!keep_acc) {
 #pragma unroll
-    for (int ti = 0; ti < WI; ++ti)
+        for (int ti = 0; ti < WI; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < WJ; ++tj)
+            for (int tj = 0; tj < WJ; ++tj)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[ti][tj][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[ti][tj][e] = 0.f;
+    }
     if (kt0 >= kt1) return;
 
     auto compute = [&](int buf) {
@@ -638,6 +642,89 @@ __global__ __launch_bounds__(128 * WM * KG, (WI * WJ >= 4 && BK == 16 && TP) ? 3
     }
 }
 
+// ---- per-sample contractions over a ragged batch ----------------------------------------------------------------
+// Sample b owns n_b consecutive rows of the "ragged" operands (n_b from seg_off, or a fixed count) and one slab of
+// the "dense" operand.  A workgroup computes one 64x64 tile of one sample's product with the same k-loop as above.
+//   FORM 0: C_b[n_b,J] = scale * P_b[n_b,K] Q_b[J,K]^T      P, C ragged; Q dense
+//   FORM 1: C_b[n_b,J] = scale * P_b[n_b,K] Q_b[K,J]        P, C ragged; Q dense; P's rows hold zeros from column K
+//                                                           up to the next multiple of four
+//   FORM 2: C_b[I,J] (+)= scale * (P_b[n_b,I]^T Q_b[n_b,J] + P2_b^T Q2_b)     P, Q ragged; C dense; P's rows hold
+//                                                           zeros from column I up to the next multiple of four
+struct BgemmKArgs {
+    capdec_bgemm_desc a;
+    int ni, nj, per_xcd;
+};
+
+template <int FORM>
+__global__ __launch_bounds__(256) void bgemm_kernel(BgemmKArgs k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const capdec_bgemm_desc& a = k.a;
+    constexpr int BK = 16;
+    // the tiles of a sample read the same dense slab: they run on one XCD, back to back (workgroup L belongs to XCD
+    // L & 7); a performance assumption only
+    const unsigned L = blockIdx.x;
+    const int logical = (int)(L & 7) * k.per_xcd + (int)(L >> 3);
+    const int per = k.ni * k.nj;
+    const int b = logical / per;
+    if (b >= a.B) return;
+    const int t = logical - b * per, ti = t / k.nj, tj = t - ti * k.nj;
+    int r0, n;
+    if (a.seg_off) {
+        r0 = a.seg_off[b] * a.mult;
+        n = min(a.seg_off[b + 1] * a.mult - r0, a.seg * a.mult);
+    } else {
+        r0 = b * a.seg * a.mult;
+        n = a.seg * a.mult;
+    }
+    const int i0 = ti * 64, j0 = tj * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
+    f32x16 acc[1][1];
+    const int j = j0 + wj * 32 + r;
+    if (FORM == 0 || FORM == 1) {
+        if (i0 >= n) return;
+        const float* P = a.P + (int64_t)r0 * a.ldp;
+        const float* Q = a.Q + (int64_t)b * a.dense_stride;
+        if (FORM == 0) {
+            mainloop<2, 1, 1, BK, true, false, false, 1>(P, Q, a.ldp, a.ldq, n, a.J, a.K, i0, j0, 0, (a.K + BK - 1) / BK, lds,
+                                                         acc);
+        } else {
+            const int KP = (a.K + 3) & ~3;
+            mainloop<2, 1, 1, BK, true, false, true, 1>(P, Q, a.ldp, a.ldq, n, a.J, KP, i0, j0, 0, (KP + BK - 1) / BK, lds, acc,
+                                                        false, a.K);
+        }
+        if (j >= a.J) return;
+        float* C = a.C + (int64_t)r0 * a.ldc + j;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wi * 32 + acc_row(e, h);
+            if (i < n) C[(int64_t)i * a.ldc] = acc[0][0][e] * a.scale;
+        }
+    } else {
+        if (n <= 0 && a.accumulate) return;
+        const int nI = (a.I + 3) & ~3;
+        const int nk = (max(n, 0) + BK - 1) / BK;
+        mainloop<2, 1, 1, BK, true, true, true, 1>(a.P + (int64_t)r0 * a.ldp, a.Q + (int64_t)r0 * a.ldq, a.ldp, a.ldq, nI, a.J,
+                                                   max(n, 1), i0, j0, 0, nk, lds, acc);
+        if (a.P2)
+            mainloop<2, 1, 1, BK, true, true, true, 1>(a.P2 + (int64_t)r0 * a.ldp, a.Q2 + (int64_t)r0 * a.ldq, a.ldp, a.ldq, nI,
+                                                       a.J, max(n, 1), i0, j0, 0, nk, lds, acc, true);
+        if (j >= a.J) return;
+        float* C = a.C + (int64_t)b * a.dense_stride + j;
+        float old[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wi * 32 + acc_row(e, h);
+            old[e] = (a.accumulate && i < a.I) ? C[(int64_t)i * a.ldc] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + wi * 32 + acc_row(e, h);
+            if (i < a.I) C[(int64_t)i * a.ldc] = old[e] + acc[0][0][e] * a.scale;
+        }
+    }
+}
+
 // Second stage of the fixed-order split-K: C[i,j] = epi(ws[0][i][j] + ws[1][i][j] + ... ) with the slabs added in
 // index order by one thread per element, so the sum does not depend on which workgroup finished first.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, capdec_gemm_group g,
@@ -1006,6 +1093,38 @@ int capdec_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, 
 int capdec_gemm_ex(const capdec_gemm_group* groups, int ngroups, int K, int flags, const capdec_gemm_extra* extra,
                    void* stream) {
     return capdec_launch_gemm(groups, ngroups, K, flags, (hipStream_t)stream, extra);
+}
+
+int capdec_bgemm(const capdec_bgemm_desc* a, int form, void* stream) {
+    CAPDEC_REQUIRE(a && a->P && a->Q && a->C && form >= 0 && form <= 2);
+    CAPDEC_REQUIRE(a->B >= 0 && a->I >= 1 && a->J >= 1 && a->K >= 1 && a->seg >= 1 && a->mult >= 1);
+    CAPDEC_REQUIRE((int64_t)a->seg * a->mult <= (1 << 20) && (a->P2 == nullptr) == (a->Q2 == nullptr));
+    CAPDEC_REQUIRE(form == 2 || !a->P2);
+    if (!(capdec_aligned16(a->P) && capdec_aligned16(a->Q) && capdec_aligned16(a->C) && a->ldp % 4 == 0 && a->ldq % 4 == 0 &&
+          a->dense_stride % 4 == 0 && (!a->P2 || (capdec_aligned16(a->P2) && capdec_aligned16(a->Q2)))))
+        return CAPDEC_EALIGN;
+    if (form == 0) CAPDEC_REQUIRE(a->K % 4 == 0 && a->ldp >= a->K && a->ldq >= a->K && a->ldc >= a->J);
+    if (form == 1) CAPDEC_REQUIRE(a->ldp >= ((a->K + 3) & ~3) && a->J % 4 == 0 && a->ldq >= a->J && a->ldc >= a->J);
+    if (form == 2) CAPDEC_REQUIRE(a->ldp >= ((a->I + 3) & ~3) && a->J % 4 == 0 && a->ldq >= a->J && a->ldc >= a->J);
+    if (a->B == 0) return 0;
+    BgemmKArgs k;
+    k.a = *a;
+    const int maxI = form == 2 ? a->I : a->seg * a->mult;
+    k.ni = (maxI + 63) / 64;
+    k.nj = (a->J + 63) / 64;
+    const int64_t total = (int64_t)a->B * k.ni * k.nj;
+    CAPDEC_REQUIRE(total <= (1 << 28));
+    k.per_xcd = (int)((total + 7) / 8);
+    const dim3 grid(8u * (unsigned)k.per_xcd);
+    hipStream_t s = (hipStream_t)stream;
+    if (form == 0)
+        hipLaunchKernelGGL(bgemm_kernel<0>, grid, dim3(256), (lds_floats<2, 1, 1, 16, false, false, 1>() * sizeof(float)), s, k);
+    else if (form == 1)
+        hipLaunchKernelGGL(bgemm_kernel<1>, grid, dim3(256), (lds_floats<2, 1, 1, 16, false, true, 1>() * sizeof(float)), s, k);
+    else
+        hipLaunchKernelGGL(bgemm_kernel<2>, grid, dim3(256), (lds_floats<2, 1, 1, 16, true, true, 1>() * sizeof(float)), s, k);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
 }
 
 int capdec_vocab_tiles(int V) { return (V + VOCAB_BI - 1) / VOCAB_BI; }

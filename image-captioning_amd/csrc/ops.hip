@@ -551,6 +551,42 @@ __global__ __launch_bounds__(256) void attention_long_kernel(AttnArgs a) {
     }
 }
 
+// ---- softmax over score rows held in memory (one wavefront per row) -------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* s, int64_t ld, int rows, int cols, int pad_to,
+                                                           const int32_t* live, int live_idx, int mult) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = live ? min(rows, live[live_idx] * mult) : rows;
+    if (row >= n) return;
+    float* p = s + (int64_t)row * ld;
+    float m = -INFINITY;
+    for (int j = lane; j < cols; j += 64) m = fmaxf(m, p[j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < cols; j += 64) {
+        const float e = expf(p[j] - m);
+        p[j] = e;                              // a lane re-reads only what it wrote itself
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    for (int j = lane; j < cols; j += 64) p[j] = p[j] / sum;
+    for (int j = cols + lane; j < pad_to; j += 64) p[j] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, float* dp, int64_t ld, int rows,
+                                                               int cols, int pad_to, float scale, const int32_t* live,
+                                                               int live_idx, int mult) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = live ? min(rows, live[live_idx] * mult) : rows;
+    if (row >= n) return;
+    const float* pr = p + (int64_t)row * ld;
+    float* d = dp + (int64_t)row * ld;
+    float dot = 0.f;
+    for (int j = lane; j < cols; j += 64) dot += pr[j] * d[j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < cols; j += 64) d[j] = pr[j] * (d[j] - dot) * scale;
+    for (int j = cols + lane; j < pad_to; j += 64) d[j] = 0.f;
+}
+
 // ---- BatchNorm1d on [B, C] ----------------------------------------------------------------------
 // eval: fold the running statistics into a per-column scale/shift for a GEMM epilogue
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -844,6 +880,26 @@ int capdec_attention_force_row_kernel(int on) {
     return 0;
 }
 #endif
+
+int capdec_softmax_rows(float* s, int64_t ld, int rows, int cols, int pad_to, const int32_t* live, int live_idx, int mult,
+                        void* stream) {
+    CAPDEC_REQUIRE(s && rows >= 0 && cols >= 1 && pad_to >= cols && ld >= pad_to && live_idx >= 0 && mult >= 1);
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, s, ld, rows, cols,
+                       pad_to, live, live_idx, mult);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_softmax_rows_bwd(const float* p, float* dp, int64_t ld, int rows, int cols, int pad_to, float scale,
+                            const int32_t* live, int live_idx, int mult, void* stream) {
+    CAPDEC_REQUIRE(p && dp && rows >= 0 && cols >= 1 && pad_to >= cols && ld >= pad_to && live_idx >= 0 && mult >= 1);
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, p, dp, ld, rows,
+                       cols, pad_to, scale, live, live_idx, mult);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
 
 int capdec_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                    float eps, int C, float* scale, float* shift, void* stream) {

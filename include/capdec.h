@@ -99,6 +99,50 @@ typedef struct capdec_gemm_extra {
 int capdec_gemm_ex(const capdec_gemm_group* groups /*host*/, int ngroups, int K, int flags,
                    const capdec_gemm_extra* extra /*host, nullable*/, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Per-sample contractions over a ragged batch (fp32 MFMA, the k-loop of capdec_gemm).
+ *   used by the cross-attention of a training step over a long memory (S rows per sample, T << S query rows): with
+ *   the key / value projections folded onto the query side,
+ *       scores = (q_h W_k,h) mem^T / sqrt(dk),   out_h = (softmax(scores) mem) W_v,h^T + b_v,h,
+ *   which is scaled_dot_product_attention(W_q x, W_k mem, W_v mem) of transformer.py:21-27,45-60 re-associated: the
+ *   memory is contracted against H*T rows per sample instead of being projected row by row (S*E*2E multiply-adds per
+ *   sample and layer become about 2*H*T*S*E); b_k shifts every score of a row by the same amount and drops out of the
+ *   softmax, b_v passes through because the probabilities of a row sum to one.
+ * Sample b owns the rows [seg_off[b]*mult, seg_off[b+1]*mult) of the ragged operands (seg_off == NULL: the rows
+ * [b*seg*mult, (b+1)*seg*mult)), n_b of them (at most seg*mult), and the slab dense + b*dense_stride of the dense one.
+ *   CAPDEC_BGEMM_NT: C_b[n_b,J] = scale * P_b[n_b,K] Q_b[J,K]^T          P, C ragged, Q dense;  K % 4 == 0
+ *   CAPDEC_BGEMM_NN: C_b[n_b,J] = scale * P_b[n_b,K] Q_b[K,J]            P, C ragged, Q dense;  J % 4 == 0; the rows of P
+ *                                                                       hold zeros from column K to the next multiple of 4
+ *   CAPDEC_BGEMM_TN: C_b[I,J] (+)= scale * (P_b[n_b,I]^T Q_b[n_b,J] + P2_b[n_b,I]^T Q2_b[n_b,J])
+ *                                                                       P, Q (P2, Q2: nullable pair, same strides) ragged,
+ *                                                                       C dense; J % 4 == 0; the rows of P, P2 hold zeros
+ *                                                                       from column I to the next multiple of 4
+ * All pointers 16-byte aligned, ldp, ldq, dense_stride multiples of 4.  accumulate (TN only): add onto C.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct capdec_bgemm_desc {
+    const float* P; const float* Q; float* C;
+    const float* P2; const float* Q2;
+    int64_t ldp, ldq, ldc, dense_stride;
+    const int32_t* seg_off;    /* device [B+1], nullable */
+    int32_t mult, seg;         /* rows per segment unit (heads); segment length when seg_off == NULL, else its maximum */
+    int32_t B, I, J, K;        /* I: TN only; K: NT / NN only */
+    float scale;
+    int32_t accumulate;
+} capdec_bgemm_desc;
+#define CAPDEC_BGEMM_NT 0
+#define CAPDEC_BGEMM_NN 1
+#define CAPDEC_BGEMM_TN 2
+int capdec_bgemm(const capdec_bgemm_desc* d /*host*/, int form, void* stream);
+
+/* Rows of scores -> probabilities, in place (softmax over the first `cols` columns of every row; columns
+ * [cols, pad_to) are set to zero), and its backward  dp <- p * (dp - sum_j p_j dp_j) * scale  (same zero padding).
+ *   transformer.py:23-24 (F.softmax(scores, dim=-1)) for score rows held in memory, as capdec_bgemm produces them.
+ * live (nullable device scalar array + index): only the first live[live_idx]*mult rows (at most `rows`) are touched. */
+int capdec_softmax_rows(float* s, int64_t ld, int rows, int cols, int pad_to, const int32_t* live, int live_idx, int mult,
+                        void* stream);
+int capdec_softmax_rows_bwd(const float* p, float* dp, int64_t ld, int rows, int cols, int pad_to, float scale,
+                            const int32_t* live, int live_idx, int mult, void* stream);
+
 /* Vocabulary projection fused with row arg-max (logits are never written):
  *   replaces fc2 + argmax, transformer.py:137,155 and cnnrnn_model.py:84-90 (log_softmax is
  *   monotone, so the arg-max of the logits is the arg-max of the log-probabilities).

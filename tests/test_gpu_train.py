@@ -151,12 +151,13 @@ def test_softmax_nll_gradient_in_place_every_row_form(V):
     assert float(work[live:64].abs().max()) == 0.0 and bool((work[64:] == 7.0).all())
 
 
-def _run_stack(dec, enc, caps, ragged, shortcut=True):
+def _run_stack(dec, enc, caps, ragged, shortcut=True, absorb=None):
     from capdec import autograd as AG
     from capdec import ops
     ids, tgt = caps[:, :-1].contiguous(), caps[:, 1:].contiguous()
     rg = ops.RaggedRows(ids, tgt, 0) if ragged else None
-    x, tape = AG.tf_forward(dec, enc, ids, 0.0, 0, single_row_shortcut=shortcut, ragged=rg)
+    x, tape = AG.tf_forward(dec, enc, ids, 0.0, 0, single_row_shortcut=shortcut, ragged=rg, absorb_cross=absorb)
+    assert absorb is None or tape.absorbed == absorb
     if ragged:
         loss, saved = AG.vocab_loss(dec, x, rg.targets_c, rows=rg.rows)
     else:
@@ -217,6 +218,55 @@ def test_ragged_stack_equals_full_rows(B, T, S):
     floor = 1e-7 * max(float(gd.abs().max()) for gd in grads_d.values())
     for name, gd in grads_d.items():
         close(grads_r[name], gd.detach().cpu().numpy(), atol=floor, what=name)
+
+
+@pytest.mark.parametrize("S,ragged", [(2, False), (5, False), (2, True), (5, True)])
+def test_f4_folded_cross_attention_against_golden(S, ragged):
+    """The cross-attention with the key / value projections folded onto the query side (the form taken for long
+    memories), forced here on the golden fixture's short memories: loss and every gradient against the reference's."""
+    fx = load_golden("f4_decoder_forward")
+    dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
+    caps = t(fx["captions"]).cuda()
+    loss, denc, grads, _ = _run_stack(dec, t(fx[f"enc_S{S}"]).cuda(), caps, ragged, absorb=True)
+    close(loss[0], fx[f"loss_S{S}"], rtol=1e-5, what="loss")
+    close(denc, fx[f"denc_S{S}"], what="denc")
+    names = [n for n, _ in dec.named_parameters()]
+    atol = _noise_floor(fx, "grad__{}@S" + str(S), names)
+    for name in names:
+        close(grads[name], fx[f"grad__{name}@S{S}"], atol=atol, what=name)
+
+
+@pytest.mark.parametrize("B,T,S,ragged", [(16, 20, 197, True), (16, 20, 197, False), (5, 7, 65, True), (3, 33, 300, True),
+                                          (9, 4, 1000, False)])
+def test_folded_cross_attention_equals_projected_form(B, T, S, ragged):
+    """Long memories: the folded form against the form that projects the memory to keys and values (different order
+    of the same sums), on captions of every length."""
+    from capdec import autograd as AG
+    fx = load_golden("f4_decoder_forward")
+    dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
+    V, E = dec.fc2.weight.shape[0], dec.fc2.weight.shape[1]
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    caps = torch.zeros(B, T + 1, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(0, T, (1,), generator=g))
+        caps[b, 0] = 1
+        caps[b, 1:1 + n] = torch.randint(4, V, (n,), generator=g)
+        caps[b, 1 + n] = 2
+    caps[1, 1:] = 0
+    caps[2, 1:] = torch.randint(4, V, (T,), generator=g)
+    caps = caps.cuda()
+    enc = torch.randn(B, S, E, generator=g).cuda()
+    loss_p, denc_p, grads_p, _ = _run_stack(dec, enc, caps, ragged, absorb=False)
+    loss_f, denc_f, grads_f, _ = _run_stack(dec, enc, caps, ragged, absorb=True)
+    close(loss_f[0], loss_p[0].cpu().numpy(), rtol=1e-6, what="loss")
+    close(denc_f, denc_p.cpu().numpy(), what="denc")
+    floor = 1e-6 * max(float(gd.abs().max()) for gd in grads_p.values())
+    for name, gd in grads_p.items():
+        close(grads_f[name], gd.detach().cpu().numpy(), atol=floor, what=name)
+    # the choice made without forcing: folded exactly when it saves at least half of the multiply-adds
+    H = dec.num_heads
+    assert AG.cross_absorbed(197, 20, 512, 4) and not AG.cross_absorbed(64, 20, 512, 4) and not AG.cross_absorbed(1, 20, 512, 4)
+    assert AG.cross_absorbed(S, T, E, H) == (S > 64 and 2 * T * (H * S + E) <= S * E + T * S)
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,E", [(3, 4, 20, 197, 512), (2, 4, 5, 65, 64), (2, 2, 64, 300, 128), (1, 4, 33, 1000, 256)])
