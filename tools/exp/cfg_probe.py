@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "image-captioning_amd"))
 import torch
 from capdec import _lib
 
+_lib.LIB_TUNE_PATH = os.environ.get("CAPDEC_EXP_LIB", _lib.LIB_TUNE_PATH)   # an experimental build of the same library
 lib = _lib.tuning_build().__enter__()      # libcapdec_tune.so: the build that has the tile overrides
 s = torch.cuda.current_stream().cuda_stream
 E = 512
@@ -50,5 +51,8 @@ def chain(M, ngroups, cfg, reps=30):
 
 cfgs = (32, 316, 116, 11)
 print("rows x groups        " + "".join(f"cfg {c:<8d}" for c in cfgs))
-for M, ng in ((256, 1), (512, 1), (1024, 1), (1536, 1), (2048, 1), (3072, 1), (4096, 1), (1024, 3), (2048, 3), (3072, 3)):
+shapes = ((256, 1), (512, 1), (1024, 1), (1536, 1), (2048, 1), (3072, 1), (4096, 1), (1024, 3), (2048, 3), (3072, 3))
+if os.environ.get("CAPDEC_PROBE_SHORT"):
+    shapes = ((1024, 1), (1024, 3))
+for M, ng in shapes:
     print(f"M={M:5d} x{ng}:        " + "".join(f"{chain(M, ng, c):7.2f} us  " for c in cfgs), flush=True)
