@@ -79,6 +79,12 @@ int capdec_launch_layernorm_rows(const float* x, const float* add, int add_div, 
                                  const float* beta2 = nullptr, const float* add2 = nullptr, int add2_div = 1,
                                  const int32_t* add2_map = nullptr);
 // (gamma2 != NULL: y = LN2(LN1(x + add) + add2[add2_map[row] / add2_div]) in one pass over the row)
+// Two memory rows per sample: y = LN2(x1 + c1[b] + sum_h sigmoid((x1 . G[b,h] + sb[b,h]) * scale) * D[b,h]), x1 = LN1(x),
+// b = row_map[row] / map_div; G, D [B][H][E], c1 [B][E], sb [B][H] (see pair_memory_constants in engine.hip)
+int capdec_launch_layernorm_pair_rows(const float* x, const float* gamma1, const float* beta1, const float* gamma2,
+                                      const float* beta2, float eps, int Mcap, int E, float* y, const int32_t* rows_dev,
+                                      const int32_t* row_map, int map_div, const float* G, const float* D, const float* c1,
+                                      const float* sb, int H, float scale, hipStream_t s);
 int capdec_launch_attention_rows(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
                                  int64_t ldv, int64_t sv, float* out, int64_t ldo, int Rcap, int H, int Tk, int dk,
                                  int causal, const int32_t* ids, int64_t ldid, const int32_t* row_map, int map_div,

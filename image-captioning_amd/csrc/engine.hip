@@ -570,6 +570,70 @@ int project_memory(const capdec_tf_model* m, const float* enc, int B, int S, flo
     return 0;
 }
 
+// ---- two memory rows: the query-independent parts of the cross-attention block, once per call -----
+// dK = k0 - k1, dV = v0 - v1 of each sample's projected memory rows, and sb[b,h] = b_q,h . dK_h
+__global__ __launch_bounds__(256) void pair_diff_kernel(const float* __restrict__ ck, const float* __restrict__ cv,
+                                                        const float* __restrict__ bq, int B, int E, int H,
+                                                        float* __restrict__ dk_out, float* __restrict__ dv_out,
+                                                        float* __restrict__ sb) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int nv = E / 4, hv = nv / H;
+    const f32x4* k0 = reinterpret_cast<const f32x4*>(ck + (int64_t)(2 * b) * E);
+    const f32x4* v0 = reinterpret_cast<const f32x4*>(cv + (int64_t)(2 * b) * E);
+    const f32x4* bq4 = reinterpret_cast<const f32x4*>(bq);
+    f32x4* dk4 = reinterpret_cast<f32x4*>(dk_out + (int64_t)b * E);
+    f32x4* dv4 = reinterpret_cast<f32x4*>(dv_out + (int64_t)b * E);
+    for (int c = lane; c < nv; c += 64) {
+        dk4[c] = k0[c] - k0[nv + c];
+        dv4[c] = v0[c] - v0[nv + c];
+    }
+    for (int h = 0; h < H; ++h) {
+        float part = 0.f;
+        for (int c = h * hv + lane; c < (h + 1) * hv; c += 64) {
+            const f32x4 d = k0[c] - k0[nv + c], q = bq4[c];
+            part += d[0] * q[0] + d[1] * q[1] + d[2] * q[2] + d[3] * q[3];
+        }
+        for (int o = 32; o; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (lane == 0) sb[(int64_t)b * H + h] = part;
+    }
+}
+
+// Per layer: G [B][H][E] = W_q,h^T dK_h, D [B][H][E] = W_o[:, h] dV_h, c1 [B][E] = W_o v1 + b_o, sb [B][H] (the operands
+// of capdec_launch_layernorm_pair_rows).  ck, cv: the projected memory, [L][B*2][E]; dkb, dvb: scratch [B][E] each.
+int pair_memory_constants(const capdec_tf_model* m, const float* ck, const float* cv, int B, float* dkb, float* dvb,
+                          float* G, float* D, float* c1, float* sb, hipStream_t s) {
+    const int E = m->E, H = m->H, dk = E / H;
+    const size_t BE = (size_t)B * E;
+    for (int l = 0; l < m->L; ++l) {
+        const capdec_attn_w& a = m->layers[l].cross_attn;
+        const float* ckl = ck + (size_t)l * 2 * BE;
+        const float* cvl = cv + (size_t)l * 2 * BE;
+        hipLaunchKernelGGL(pair_diff_kernel, dim3((B + 3) / 4), dim3(256), 0, s, ckl, cvl, a.bq, B, E, H, dkb, dvb,
+                           sb + (size_t)l * B * H);
+        CAPDEC_LAUNCH_CHECK();
+        for (int h0 = 0; h0 < H; h0 += 4) {
+            const int n = H - h0 < 4 ? H - h0 : 4;
+            capdec_gemm_group gg[4], gd[4];
+            for (int i = 0; i < n; ++i) {
+                const int h = h0 + i;
+                // G_h[b, e] = sum_d dK[b, h*dk + d] W_q[h*dk + d, e]: the rows h*dk.. of W_q are its [k][j] image
+                gg[i] = linear_group(dkb + h * dk, E, B, a.wq + (size_t)h * dk * E, nullptr, E,
+                                     G + (size_t)l * BE * H + (size_t)h * E, (int64_t)H * E);
+                gg[i].ldq = E;
+                // D_h[b, e] = sum_d dV[b, h*dk + d] W_o[e, h*dk + d]
+                gd[i] = linear_group(dvb + h * dk, E, B, a.wo + h * dk, nullptr, E, D + (size_t)l * BE * H + (size_t)h * E,
+                                     (int64_t)H * E);
+                gd[i].ldq = E;
+            }
+            CAPDEC_TRY(capdec_launch_gemm(gg, n, dk, CAPDEC_GEMM_TQ, s));
+            CAPDEC_TRY(capdec_launch_gemm(gd, n, dk, 0, s));
+        }
+        CAPDEC_TRY(linear(cvl + E, 2 * E, B, a.wo, a.bo, E, E, c1 + (size_t)l * BE, E, nullptr, 0, 0, s));
+    }
+    return 0;
+}
+
 // ---- decoder stack over a block of rows ------------------------------------------------------
 // Full-prefix form: X [B*T,E] in, X out (post-LN); every position of every sample is recomputed.
 struct FullBufs {
@@ -623,7 +687,8 @@ struct DecodeWs {
     float *x, *y, *x1, *x2, *q, *ao, *hb;   // [Mcap][E], Mcap = B + extra_cap
     float *kc, *vc;          // [L][B][max_len][E]
     float *ck, *cv;          // [L][B*S][E]
-    float *cc;               // [L][B][E]  S == 1: the whole cross-attention block output per sample
+    float *cc;               // [L][B][E]  S == 1: the whole cross-attention block output per sample (S == 2: c1)
+    float *pg, *pd, *psb;    // S == 2: [L][B][H][E] x2 and [L][B][H], see pair_memory_constants
     float* pval; int32_t* pidx;
     int32_t *tok, *done, *first_pad;
     int32_t *rowmap;         // [max_len][Mcap]
@@ -645,6 +710,12 @@ static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, 
     d.ck = c.take<float>((size_t)m->L * BE * S);
     d.cv = c.take<float>((size_t)m->L * BE * S);
     d.cc = c.take<float>((size_t)m->L * BE);
+    d.pg = d.pd = d.psb = nullptr;
+    if (S == 2) {
+        d.pg = c.take<float>((size_t)m->L * BE * m->H);
+        d.pd = c.take<float>((size_t)m->L * BE * m->H);
+        d.psb = c.take<float>((size_t)m->L * B * m->H);
+    }
     const size_t nt = (size_t)capdec_vocab_tiles(m->V);
     d.pval = c.take<float>(capdec_part_elems(B, (int)nt));
     d.pidx = c.take<int32_t>(capdec_part_elems(B, (int)nt));
@@ -791,6 +862,7 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
     const int64_t ldtok = max_len + 1;
     const size_t BE = (size_t)B * E;
     const bool s1 = (S == 1) && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT);
+    const bool s2 = (S == 2) && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT);
 
     hipLaunchKernelGGL(cached_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, w.first_pad, out_ids,
                        out_len, out_dirty, w.rowmap, w.nrows, B, max_len, sos);
@@ -807,6 +879,8 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
         }
     } else {
         CAPDEC_TRY(project_memory(m, enc, B, S, w.ck, w.cv, s));
+        // two keys: the block is a per-sample constant plus H logistic gates (w.q / w.ao are free until the first step)
+        if (s2) CAPDEC_TRY(pair_memory_constants(m, w.ck, w.cv, B, w.q, w.ao, w.pg, w.pd, w.cc, w.psb, s));
     }
 
     const int nt = capdec_vocab_tiles(V);
@@ -834,6 +908,12 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
                 // norm1 and norm2 in one pass: the cross-attention sub-layer is the per-sample constant cc
                 CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, Mcap, E, w.x2,
                                                         rows, s, ly.n2_g, ly.n2_b, w.cc + l * BE, max_len, map));
+            } else if (s2) {
+                // norm1, the two-key cross-attention block and norm2 in one pass over the row
+                CAPDEC_TRY(capdec_launch_layernorm_pair_rows(w.y, ly.n1_g, ly.n1_b, ly.n2_g, ly.n2_b, 1e-5f, Mcap, E, w.x2,
+                                                             rows, map, max_len, w.pg + (size_t)l * BE * H,
+                                                             w.pd + (size_t)l * BE * H, w.cc + l * BE,
+                                                             w.psb + (size_t)l * B * H, H, 1.0f / sqrtf((float)dk), s));
             } else {
                 CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, Mcap, E, w.x1,
                                                         rows, s));

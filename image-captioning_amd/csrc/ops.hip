@@ -144,6 +144,111 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     }
 }
 
+// Cross-attention over exactly two memory rows, folded into the two LayerNorms around it.  The softmax over two keys is
+// a logistic function of the score difference, so per sample and layer everything that does not depend on the query is
+// a constant: with dK = k0 - k1, dV = v0 - v1 (projected memory rows),
+//   p_h  = sigmoid(((W_q x1 + b_q)_h . dK_h) / sqrt(dk)) = sigmoid((x1 . G_h + sb_h) / sqrt(dk)),  G_h = W_q,h^T dK_h
+//   attn = W_o (v1 + p (.) dV) + b_o = c1 + sum_h p_h D_h,   c1 = W_o v1 + b_o,  D_h = W_o[:, h] dV_h
+// (transformer.py:21-27,45-60,86 with Tk = 2).  One wavefront per row: x1 = LN1(x) stays in registers.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_pair_kernel(const float* __restrict__ x, const float* __restrict__ gamma1,
+                                                      const float* __restrict__ beta1, const float* __restrict__ gamma2,
+                                                      const float* __restrict__ beta2, float eps, int M, int E,
+                                                      float* __restrict__ y, const int32_t* __restrict__ rows_dev,
+                                                      const int32_t* __restrict__ row_map, int map_div,
+                                                      const float* __restrict__ G, const float* __restrict__ D,
+                                                      const float* __restrict__ c1, const float* __restrict__ sb, int H,
+                                                      float scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M || (rows_dev && row >= rows_dev[0])) return;
+    const int nv = E / 4;
+    const int b = (row_map ? row_map[row] : row) / map_div;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * E);
+    f32x4 v[NV], a2[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = lane + 64 * u;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            v[u] = xr[c];
+            s += v[u][0] + v[u][1] + v[u][2] + v[u][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nv) {
+            v[u] -= mean;
+            q += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma1);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(beta1);
+    const f32x4* c4 = reinterpret_cast<const f32x4*>(c1 + (int64_t)b * E);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = lane + 64 * u;
+        a2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            v[u] = v[u] * rstd * g4[c] + b4[c];          // x1
+            a2[u] = c4[c];
+        }
+    }
+    for (int h = 0; h < H; ++h) {
+        const f32x4* gh = reinterpret_cast<const f32x4*>(G + ((int64_t)b * H + h) * E);
+        const f32x4* dh = reinterpret_cast<const f32x4*>(D + ((int64_t)b * H + h) * E);
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nv) {
+                const f32x4 g = gh[c];
+                part += v[u][0] * g[0] + v[u][1] * g[1] + v[u][2] * g[2] + v[u][3] * g[3];
+            }
+        }
+        const float z = (wave_sum(part) + sb[(int64_t)b * H + h]) * scale;
+        const float p = 1.0f / (1.0f + expf(-z));
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nv) a2[u] += dh[c] * p;
+        }
+    }
+    float s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nv) {
+            v[u] += a2[u];
+            s2 += v[u][0] + v[u][1] + v[u][2] + v[u][3];
+        }
+    }
+    const float mean2 = wave_sum(s2) / (float)E;
+    float q2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nv) {
+            v[u] -= mean2;
+            q2 += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+        }
+    }
+    const float rstd2 = 1.0f / sqrtf(wave_sum(q2) / (float)E + eps);
+    const f32x4* g24 = reinterpret_cast<const f32x4*>(gamma2);
+    const f32x4* b24 = reinterpret_cast<const f32x4*>(beta2);
+    f32x4* yr = reinterpret_cast<f32x4*>(y + (int64_t)row * E);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nv) yr[c] = v[u] * rstd2 * g24[c] + b24[c];
+    }
+}
+
 // ---- fused attention, one wavefront per (b, h, query row) ---------------------------------------
 struct AttnArgs {
     const float* q; int64_t ldq;
@@ -681,6 +786,20 @@ int capdec_launch_layernorm_rows(const float* x, const float* add, int add_div, 
     hipLaunchKernelGGL(add_layernorm_kernel<NV_>, dim3((Mcap + 3) / 4), dim3(256), 0, s, x, add, add ? add_div : 1, \
                        gamma, beta, eps, Mcap, E, y, (float*)nullptr, (float*)nullptr, add_map, rows_dev, gamma2,   \
                        beta2, add2, add2_div, add2_map)
+    CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
+#undef CAPDEC_CALL
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_launch_layernorm_pair_rows(const float* x, const float* gamma1, const float* beta1, const float* gamma2,
+                                      const float* beta2, float eps, int Mcap, int E, float* y, const int32_t* rows_dev,
+                                      const int32_t* row_map, int map_div, const float* G, const float* D, const float* c1,
+                                      const float* sb, int H, float scale, hipStream_t s) {
+    if (Mcap == 0) return 0;
+#define CAPDEC_CALL(NV_)                                                                                             \
+    hipLaunchKernelGGL(ln_pair_kernel<NV_>, dim3((Mcap + 3) / 4), dim3(256), 0, s, x, gamma1, beta1, gamma2, beta2, eps, \
+                       Mcap, E, y, rows_dev, row_map, map_div, G, D, c1, sb, H, scale)
     CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();

@@ -435,7 +435,9 @@ int capdec_event_destroy(void* ev);
 int capdec_event_record(void* ev, void* stream);
 int capdec_event_elapsed_ms(void* begin, void* end, float* ms);
 
-#define CAPDEC_DECODE_NO_S1_SHORTCUT 1   /* run the general cross-attention kernels even when S == 1 */
+#define CAPDEC_DECODE_NO_S1_SHORTCUT 1   /* run the general cross-attention kernels even when S == 1 or S == 2 (the
+                                            closed forms: one key -> the block is a per-sample constant; two keys ->
+                                            a per-sample constant plus one logistic gate per head) */
 int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, int S, int max_len, int sos, int eos,
                             int flags, int extra_cap, void* workspace, size_t workspace_bytes, int64_t* out_ids,
                             int32_t* out_len, int32_t* out_dirty, const capdec_probe* probe /*nullable*/, void* stream);

@@ -284,6 +284,25 @@ def test_f5_greedy_random_weights_cached_and_exact():
             check_greedy(got, sd, enc, int(fx["H"]), 12, want_rows=want)
 
 
+def test_two_memory_rows_closed_form_against_the_oracle_and_the_general_kernels():
+    """S = 2 (the ViT+CNN and YOLO+CNN heads): the cached decoder folds the cross-attention block into the LayerNorms
+    around it (a per-sample constant plus one logistic gate per head).  Same tokens as the oracle (near-ties aside) and
+    as the general cross-attention kernels, at the benchmark's widths."""
+    torch.manual_seed(5)
+    dec = plain_decoder(512, 10000, 4, 2).cuda().eval()
+    g = torch.Generator().manual_seed(77)
+    enc = torch.randn(24, 2, 512, generator=g)
+    got, _ = _greedy(dec, enc, 12)
+    check_greedy(got, cpu_sd(dec), enc, 4, 12)
+    general, _ = _greedy(dec, enc, 12, no_s1_shortcut=True)
+    same = sum(a == b for a, b in zip(got, general))
+    assert same >= 23, f"{same} of 24 rows equal"
+    # memory rows that differ a lot (saturated gates) and rows that are equal (gate exactly one half)
+    enc2 = torch.cat([enc[:8] * 30.0, enc[8:16, :1].expand(8, 2, 512)], 0).contiguous()
+    got2, _ = _greedy(dec, enc2, 12)
+    check_greedy(got2, cpu_sd(dec), enc2, 4, 12)
+
+
 def test_greedy_outputs_packed_on_the_device_and_prebuilt_parameter_struct():
     """ids, lengths and flags share one device allocation: the host copies (one pinned transfer), the device views
     (to_cpu=False, what a cross-rank gather takes) and a call through a parameter struct built once must agree."""
