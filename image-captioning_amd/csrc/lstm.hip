@@ -300,6 +300,92 @@ __global__ __launch_bounds__(256) void lstm_step_dma_kernel(LstmArgs a) {
     }
 }
 
+// ---- small batches (B <= 32: the reference's own CPU-sized decode, cnnrnn_model.py:57-110 at batch 32) ---------------
+// At 32 samples the tiling above has Hd/64 workgroups (8 at Hd = 512) whose wavefronts each walk the whole 768-deep
+// contraction: 768 dependent MFMAs, 20 us, on 32 of the chip's 1024 SIMDs.  Here a workgroup owns 8 hidden units: the 32
+// columns of one accumulator are (gate, unit) = (j / 8, j % 8), so a single 32x32 tile holds all four gates of its
+// units for all samples, and the workgroup's four wavefronts split the contraction four ways (each reads its own k
+// range of the operands straight from memory into MFMA fragments: nothing is shared between them, so no LDS
+// staging); the partial tiles meet in LDS, where one thread per (sample, unit) adds them and applies the cell update.
+// Hd/8 workgroups (64 at Hd = 512), 192 MFMAs per wavefront.
+__global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmArgs a) {
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int u0 = blockIdx.x * 8;
+    const int nkx = a.E / 8, nkh = a.h0 ? a.Hd / 8 : 0, nk = nkx + nkh;    // k-chunks of 8
+    const int per = (nk + 3) / 4;
+    const int kc0 = wave * per, kc1 = min(nk, kc0 + per);
+    const int arow = min(r, a.B - 1);                       // rows past the batch repeat the last one: never stored
+    const int wrow = (r >> 3) * a.Hd + min(u0 + (r & 7), a.Hd - 1);
+    const float* xa = a.x + (int64_t)arow * a.ldx + 4 * h;
+    const float* ha = a.h0 ? a.h0 + (int64_t)arow * a.ldh0 + 4 * h : nullptr;
+    const float* wx = a.w_ih + (int64_t)wrow * a.E + 4 * h;
+    const float* wh = a.w_hh + (int64_t)wrow * a.Hd + 4 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    constexpr int U = 4;                                     // k-chunks per batch of loads
+    f32x4 av[2][U], bv[2][U];
+    auto fetch = [&](int set, int kc) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int k = kc + i;
+            av[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < kc1) {
+                if (k < nkx) {
+                    av[set][i] = *reinterpret_cast<const f32x4*>(xa + 8 * k);
+                    bv[set][i] = *reinterpret_cast<const f32x4*>(wx + 8 * k);
+                } else {
+                    av[set][i] = *reinterpret_cast<const f32x4*>(ha + 8 * (k - nkx));
+                    bv[set][i] = *reinterpret_cast<const f32x4*>(wh + 8 * (k - nkx));
+                }
+            }
+        }
+    };
+    auto multiply = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < U; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][i][m], bv[set][i][m], acc, 0, 0, 0);
+    };
+    // the loads of the next batch are in flight while the current one is multiplied
+    fetch(0, kc0);
+    for (int kc = kc0; kc < kc1; kc += 2 * U) {
+        fetch(1, kc + U);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0, kc + 2 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave][e][lane] = acc[e];
+    __syncthreads();
+    // thread -> (sample i, unit ul); gate g of that pair sits in register e(i), lane 32 * h(i) + 8 * g + ul of every partial
+    const int i = tid >> 3, ul = tid & 7, u = u0 + ul;
+    if (i >= a.B || u >= a.Hd) return;
+    const int e = (i & 3) + 4 * (i >> 3), hl = ((i >> 2) & 1) * 32 + ul;
+    float gate[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int l = hl + 8 * g;
+        gate[g] = ((red[0][e][l] + red[1][e][l]) + (red[2][e][l] + red[3][e][l])) + (a.b_ih[g * a.Hd + u] + a.b_hh[g * a.Hd + u]);
+    }
+    const float cp = a.c0 ? a.c0[(int64_t)i * a.Hd + u] : 0.f;
+    const float cn = sigmoidf_(gate[1]) * cp + sigmoidf_(gate[0]) * tanhf(gate[2]);
+    const float hn = sigmoidf_(gate[3]) * tanhf(cn);
+    a.c1[(int64_t)i * a.Hd + u] = cn;
+    a.h1[(int64_t)i * a.ldh1 + u] = hn;
+    if (a.gates) {
+        float* gp = a.gates + (int64_t)i * 4 * a.Hd + u;
+        gp[0] = gate[0]; gp[a.Hd] = gate[1]; gp[2 * a.Hd] = gate[2]; gp[3 * a.Hd] = gate[3];
+    }
+}
+
 struct LstmBwdArgs {
     const float* gates; const float* c0; const float* c1;
     const float* dh_out; int64_t lddh; const float* dh_rec; const float* dc_in;
@@ -361,6 +447,11 @@ extern "C" int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, in
         hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
     if (!ready) return CAPDEC_EINVAL;
+    if (B <= 32 && vec && E % 8 == 0 && Hd % 8 == 0 && g_lstm_staging != 1) {
+        hipLaunchKernelGGL(lstm_step_small_kernel, dim3(Hd / 8), dim3(256), 0, (hipStream_t)stream, a);
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid((Hd + TU - 1) / TU, (B + TB - 1) / TB);
     if (vec && E % BK == 0 && Hd % BK == 0 && g_lstm_staging != 1) {
         constexpr size_t smem_dma = LSTM_DMA_LDS_FLOATS * sizeof(float);

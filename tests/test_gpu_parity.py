@@ -263,6 +263,41 @@ def test_f10_medium_decoder_default_init():
     check_greedy(ids_to_lists(ids, lengths), cpu_sd(dec), t(fx["enc"]), 4, 8, want_rows=unpad(fx["greedy_ids"]))
 
 
+@pytest.mark.parametrize("B,E,Hd", [(1, 256, 512), (7, 64, 96), (32, 256, 512), (32, 1024, 512), (20, 8, 8), (31, 40, 24)])
+def test_lstm_step_small_batch_kernel(ops, B, E, Hd, tuning_lib):
+    """Up to 32 samples (the CNN-RNN decode as the reference runs it, batch 32) take the kernel that gives a workgroup 8
+    hidden units and splits the contraction over its wavefronts: against the fp64 cell equations (cnnrnn_model.py:17,
+    29-30) and, within rounding, against the large-batch kernel."""
+    lib = tuning_lib
+    g = torch.Generator().manual_seed(B * 7 + E)
+    x, h0, c0 = (torch.randn(B, n, generator=g) for n in (E, Hd, Hd))
+    w_ih, w_hh = torch.randn(4 * Hd, E, generator=g) * E ** -0.5, torch.randn(4 * Hd, Hd, generator=g) * Hd ** -0.5
+    b_ih, b_hh = torch.randn(4 * Hd, generator=g), torch.randn(4 * Hd, generator=g)
+    gates = x.double() @ w_ih.double().t() + b_ih.double() + h0.double() @ w_hh.double().t() + b_hh.double()
+    gi, gf, gg, go = gates.split(Hd, dim=1)
+    c_ref = torch.sigmoid(gf) * c0.double() + torch.sigmoid(gi) * torch.tanh(gg)
+    h_ref = torch.sigmoid(go) * torch.tanh(c_ref)
+    args = [v.cuda() for v in (x, h0, c0, w_ih, w_hh, b_ih, b_hh)]
+    h1, c1, gt = ops.lstm_step(*args, want_gates=True)
+    close(h1, h_ref, what="h")
+    close(c1, c_ref, what="c")
+    close(gt, gates, what="gates")
+    # no previous state: the recurrent half of the contraction is skipped
+    h1z, c1z = ops.lstm_step(args[0], None, None, *args[3:])
+    gz = x.double() @ w_ih.double().t() + b_ih.double() + b_hh.double()
+    zi, zf, zg, zo = gz.split(Hd, dim=1)
+    cz = torch.sigmoid(zi) * torch.tanh(zg)
+    close(c1z, cz, what="c from a zero state")
+    close(h1z, torch.sigmoid(zo) * torch.tanh(cz), what="h from a zero state")
+    try:
+        lib.capdec_lstm_force_staging(1)         # the large-batch, register-staged kernel
+        h1b, c1b, gtb = ops.lstm_step(*args, want_gates=True)
+    finally:
+        lib.capdec_lstm_force_staging(0)
+    close(h1, h1b.cpu().numpy(), rtol=1e-5, what="h, small against large-batch kernel")
+    close(gt, gtb.cpu().numpy(), rtol=1e-5, what="gates, small against large-batch kernel")
+
+
 # ---------------------------------------------------------------------------------------------
 # greedy decode
 # ---------------------------------------------------------------------------------------------
