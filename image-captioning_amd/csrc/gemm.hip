@@ -655,8 +655,10 @@ struct BgemmKArgs {
     int ni, nj, per_xcd;
 };
 
-template <int FORM>
-__global__ __launch_bounds__(256) void bgemm_kernel(BgemmKArgs k) {
+// WM = 2: 64x64 tiles (256 threads); WM = 1: 32x64 tiles (128 threads), for the forms whose row count is the ragged
+// one (at most H*T = 80 rows per sample: three 32-row tiles instead of two 64-row ones, a quarter fewer MFMAs).
+template <int FORM, int WM>
+__global__ __launch_bounds__(128 * WM) void bgemm_kernel(BgemmKArgs k) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const capdec_bgemm_desc& a = k.a;
     constexpr int BK = 16;
@@ -676,9 +678,9 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmKArgs k) {
         r0 = b * a.seg * a.mult;
         n = a.seg * a.mult;
     }
-    const int i0 = ti * 64, j0 = tj * 64;
+    const int i0 = ti * 32 * WM, j0 = tj * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
+    const int wi = WM == 2 ? wave >> 1 : 0, wj = wave & 1, r = lane & 31, h = lane >> 5;
     f32x16 acc[1][1];
     const int j = j0 + wj * 32 + r;
     if (FORM == 0 || FORM == 1) {
@@ -686,11 +688,11 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmKArgs k) {
         const float* P = a.P + (int64_t)r0 * a.ldp;
         const float* Q = a.Q + (int64_t)b * a.dense_stride;
         if (FORM == 0) {
-            mainloop<2, 1, 1, BK, true, false, false, 1>(P, Q, a.ldp, a.ldq, n, a.J, a.K, i0, j0, 0, (a.K + BK - 1) / BK, lds,
+            mainloop<WM, 1, 1, BK, true, false, false, 1>(P, Q, a.ldp, a.ldq, n, a.J, a.K, i0, j0, 0, (a.K + BK - 1) / BK, lds,
                                                          acc);
         } else {
             const int KP = (a.K + 3) & ~3;
-            mainloop<2, 1, 1, BK, true, false, true, 1>(P, Q, a.ldp, a.ldq, n, a.J, KP, i0, j0, 0, (KP + BK - 1) / BK, lds, acc,
+            mainloop<WM, 1, 1, BK, true, false, true, 1>(P, Q, a.ldp, a.ldq, n, a.J, KP, i0, j0, 0, (KP + BK - 1) / BK, lds, acc,
                                                         false, a.K);
         }
         if (j >= a.J) return;
@@ -704,10 +706,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmKArgs k) {
         if (n <= 0 && a.accumulate) return;
         const int nI = (a.I + 3) & ~3;
         const int nk = (max(n, 0) + BK - 1) / BK;
-        mainloop<2, 1, 1, BK, true, true, true, 1>(a.P + (int64_t)r0 * a.ldp, a.Q + (int64_t)r0 * a.ldq, a.ldp, a.ldq, nI, a.J,
+        mainloop<WM, 1, 1, BK, true, true, true, 1>(a.P + (int64_t)r0 * a.ldp, a.Q + (int64_t)r0 * a.ldq, a.ldp, a.ldq, nI, a.J,
                                                    max(n, 1), i0, j0, 0, nk, lds, acc);
         if (a.P2)
-            mainloop<2, 1, 1, BK, true, true, true, 1>(a.P2 + (int64_t)r0 * a.ldp, a.Q2 + (int64_t)r0 * a.ldq, a.ldp, a.ldq, nI,
+            mainloop<WM, 1, 1, BK, true, true, true, 1>(a.P2 + (int64_t)r0 * a.ldp, a.Q2 + (int64_t)r0 * a.ldq, a.ldp, a.ldq, nI,
                                                        a.J, max(n, 1), i0, j0, 0, nk, lds, acc, true);
         if (j >= a.J) return;
         float* C = a.C + (int64_t)b * a.dense_stride + j;
@@ -1110,7 +1112,7 @@ int capdec_bgemm(const capdec_bgemm_desc* a, int form, void* stream) {
     BgemmKArgs k;
     k.a = *a;
     const int maxI = form == 2 ? a->I : a->seg * a->mult;
-    k.ni = (maxI + 63) / 64;
+    k.ni = form == 2 ? (maxI + 63) / 64 : (maxI + 31) / 32;
     k.nj = (a->J + 63) / 64;
     const int64_t total = (int64_t)a->B * k.ni * k.nj;
     CAPDEC_REQUIRE(total <= (1 << 28));
@@ -1118,11 +1120,11 @@ int capdec_bgemm(const capdec_bgemm_desc* a, int form, void* stream) {
     const dim3 grid(8u * (unsigned)k.per_xcd);
     hipStream_t s = (hipStream_t)stream;
     if (form == 0)
-        hipLaunchKernelGGL(bgemm_kernel<0>, grid, dim3(256), (lds_floats<2, 1, 1, 16, false, false, 1>() * sizeof(float)), s, k);
+        hipLaunchKernelGGL((bgemm_kernel<0, 1>), grid, dim3(128), (lds_floats<1, 1, 1, 16, false, false, 1>() * sizeof(float)), s, k);
     else if (form == 1)
-        hipLaunchKernelGGL(bgemm_kernel<1>, grid, dim3(256), (lds_floats<2, 1, 1, 16, false, true, 1>() * sizeof(float)), s, k);
+        hipLaunchKernelGGL((bgemm_kernel<1, 1>), grid, dim3(128), (lds_floats<1, 1, 1, 16, false, true, 1>() * sizeof(float)), s, k);
     else
-        hipLaunchKernelGGL(bgemm_kernel<2>, grid, dim3(256), (lds_floats<2, 1, 1, 16, true, true, 1>() * sizeof(float)), s, k);
+        hipLaunchKernelGGL((bgemm_kernel<2, 2>), grid, dim3(256), (lds_floats<2, 1, 1, 16, true, true, 1>() * sizeof(float)), s, k);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

@@ -96,6 +96,22 @@ def main():
         lambda: ops.attention(q, km, vm, Bt, H, Tt, St, want_lse=True))
     hbm("attn_bwd_chunked_kernel (197 memory rows)", "B=512,H=4,Tq=20,Tk=197", (4.0 * Mt + 4.0 * Bt * St) * E * 4,
         lambda: ops.attention_bwd(q, km, vm, dy, lse2, Bt, H, Tt, St, out=o2))
+    # the same cross-attention with the key / value projections folded onto the query side: per-sample contractions
+    # of the H*T query rows against the raw memory (S=197, 512 samples, all 20 positions live)
+    R4 = Mt * H
+    qp, mem = rnd(R4, E), rnd(Bt * St, E)
+    pbuf = torch.zeros(R4, 224, device="cuda")
+    cbuf = torch.zeros(R4, E, device="cuda")
+    dmem = torch.zeros(Bt * St, E, device="cuda")
+    mfma("bgemm_kernel<NT> (scores = (q W_k) mem^T)", "512 x [80x197x512]", 2.0 * R4 * St * E,
+         lambda: ops.bgemm("nt", qp, mem, pbuf, Bt, Tt, H, scale=0.0884))
+    hbm("softmax_rows_kernel", "40960x197", 2.0 * R4 * St * 4, lambda: ops.softmax_rows_(pbuf, St))
+    mfma("bgemm_kernel<NN> (context = P mem)", "512 x [80x512x197]", 2.0 * R4 * St * E,
+         lambda: ops.bgemm("nn", pbuf, mem, cbuf, Bt, Tt, H))
+    dpb = torch.zeros(R4, 224, device="cuda")
+    hbm("softmax_rows_bwd_kernel", "40960x197", 3.0 * R4 * St * 4, lambda: ops.softmax_rows_bwd_(pbuf, dpb, St, scale=0.0884))
+    mfma("bgemm_kernel<TN> (d mem += P^T dC + dS^T q')", "512 x [197x512x160]", 4.0 * R4 * St * E,
+         lambda: ops.bgemm("tn", pbuf, cbuf, dmem, Bt, Tt, H, P2=dpb, Q2=qp, accumulate=True))
     bias_g = torch.zeros(E, device="cuda")
     hbm("colsum_kernel (bias gradient)", "10240x512", 1.0 * Mt * E * 4, lambda: ops.colsum(dy, bias_g))
     hbm("group_sum_kernel", "512x20x512", 1.0 * Mt * E * 4, lambda: ops.group_sum(dy, Tt))
@@ -115,6 +131,11 @@ def main():
     wih, whh, bih, bhh = rnd(4 * Hd, Er), rnd(4 * Hd, Hd), rnd(4 * Hd), rnd(4 * Hd)
     mfma("lstm_step_kernel (gates + cell)", "B=1024,E=256,Hd=512", 2.0 * Br * (Er + Hd) * 4 * Hd,
          lambda: ops.lstm_step(xr, h0, c0, wih, whh, bih, bhh))
+    x32, h32, c32 = rnd(32, Er), rnd(32, Hd), rnd(32, Hd)
+    mfma("lstm_step_small_kernel (gates + cell, batch 32)", "B=32,E=256,Hd=512", 2.0 * 32 * (Er + Hd) * 4 * Hd,
+         lambda: ops.lstm_step(x32, h32, c32, wih, whh, bih, bhh))
+    Wv5, bv5, x5 = rnd(5000, Hd), rnd(5000), rnd(32, Hd)
+    mfma("vocab_reduce_kernel (batch 32, V=5000)", "32x5000x512", 2.0 * 32 * 5000 * Hd, lambda: ops.vocab_argmax(x5, Wv5, bv5))
     Bs, Ss, As = 1024, 64, 512
     u, pfm, vv, encm = rnd(Bs, As), rnd(Bs * Ss, As), rnd(As), rnd(Bs * Ss, E)
     ctx = torch.empty(Bs, E, device="cuda")
