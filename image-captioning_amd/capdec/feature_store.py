@@ -132,15 +132,34 @@ class _TensorOnlyUnpickler:
             return U(fh).load()
 
 
+def _feature_vector(path):
+    """One per-image feature file as a flat fp32 numpy vector; anything but a floating-point tensor is refused."""
+    obj = _TensorOnlyUnpickler.load(path)
+    if not isinstance(obj, torch.Tensor) or not obj.is_floating_point():
+        raise ValueError(f"{path}: expected a floating-point tensor, found {type(obj).__name__}"
+                         + (f" of dtype {obj.dtype}" if isinstance(obj, torch.Tensor) else ""))
+    return obj.detach().to(torch.float32).reshape(-1).contiguous().numpy()
+
+
 def import_pickle_dir(src_dir, dst_root):
-    """Convert a directory of the reference's ``{image}.pkl`` feature files (your own precompute output) into a
-    store.  Only tensor-rebuild callables are honoured while reading; anything else in a file aborts the import."""
-    names = sorted(n for n in os.listdir(src_dir) if n.endswith(".pkl"))
+    """Convert a directory of the reference's ``{image}.pkl`` feature files into a store.
+
+    The directory must be the output of YOUR OWN precompute run (reference train.py:37-93): the files are read with a
+    pickle machine restricted to the tensor-rebuild callables such files contain (anything else aborts the import), which
+    is a guard against accidents, not a sandbox for files of unknown origin.  Only regular files directly under
+    ``src_dir`` are read (no symbolic links, no sub-directories); every file must hold one floating-point tensor, stored
+    as fp32, and all of them the same number of elements."""
+    src_dir = os.path.abspath(src_dir)
+    names = sorted(n for n in os.listdir(src_dir)
+                   if n.endswith(".pkl") and os.path.isfile(os.path.join(src_dir, n)) and not os.path.islink(os.path.join(src_dir, n)))
     if not names:
         raise ValueError(f"no .pkl files under {src_dir}")
-    first = _TensorOnlyUnpickler.load(os.path.join(src_dir, names[0])).reshape(-1)
-    store = FeatureStore.create(dst_root, [n[:-4] for n in names], first.numel())
+    first = _feature_vector(os.path.join(src_dir, names[0]))
+    store = FeatureStore.create(dst_root, [n[:-4] for n in names], first.size)
     for i, n in enumerate(names):
-        store.data[i] = _TensorOnlyUnpickler.load(os.path.join(src_dir, n)).reshape(-1).numpy()
+        vec = first if i == 0 else _feature_vector(os.path.join(src_dir, n))
+        if vec.size != first.size:
+            raise ValueError(f"{n}: {vec.size} elements, the first file has {first.size}")
+        store.data[i] = vec
     store.data.flush()
     return store

@@ -180,6 +180,23 @@ def test_feature_store_roundtrip_and_batches(tmp_path):
         pickle.dump(os.system, fh)
     with pytest.raises(Exception):
         import_pickle_dir(str(src), str(tmp_path / "s3"))
+    os.remove(src / "evil.pkl")
+    # a non-tensor payload, a vector of another length and a link out of the directory: refused or skipped
+    with open(src / "zz_list.pkl", "wb") as fh:
+        pickle.dump([1.0, 2.0], fh)
+    with pytest.raises(ValueError, match="expected a floating-point tensor"):
+        import_pickle_dir(str(src), str(tmp_path / "s4"))
+    os.remove(src / "zz_list.pkl")
+    with open(src / "zz_short.pkl", "wb") as fh:
+        pickle.dump(torch.zeros(3), fh)
+    with pytest.raises(ValueError, match="elements"):
+        import_pickle_dir(str(src), str(tmp_path / "s5"))
+    os.remove(src / "zz_short.pkl")
+    outside = tmp_path / "outside.pkl"
+    with open(outside, "wb") as fh:
+        pickle.dump(torch.zeros(24), fh)
+    os.symlink(outside, src / "zz_link.pkl")
+    assert len(import_pickle_dir(str(src), str(tmp_path / "s6"))) == 5
 
 
 def test_reference_checkpoint_load_filters_backbone(tmp_path):
