@@ -619,17 +619,26 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         del model
-        train = train_bench(device, rank, world, args.train_steps, args.warmup, fence, note, with_roofline=rank == 0)
+        # (an exception in a training leg is reported in the line instead of the leg's numbers: it must not cost the
+        #  decode result either; a rank that fails alone leaves the others in a collective, which the watchdog ends)
+        train_ok = True
+        try:
+            train = train_bench(device, rank, world, args.train_steps, args.warmup, fence, note, with_roofline=rank == 0)
+        except Exception as e:                                   # noqa: BLE001
+            train, train_ok = {"error": f"rank {rank}: {type(e).__name__}: {e}"}, False
         watchdog.cancel()
         note("train timed")
         if rank == 0:
             out["train"] = train
-        if DIST_ON:
+        if DIST_ON and train_ok:
             # the same global batch of 512 sharded over the ranks (the other reading of "data parallel")
             watchdog = threading.Timer(args.train_budget, give_up)
             watchdog.daemon = True
             watchdog.start()
-            strong = train_bench(device, rank, world, args.train_steps, args.warmup, fence, note, strong=True)
+            try:
+                strong = train_bench(device, rank, world, args.train_steps, args.warmup, fence, note, strong=True)
+            except Exception as e:                               # noqa: BLE001
+                strong = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
             watchdog.cancel()
             if rank == 0:
                 out["train_strong"] = strong
