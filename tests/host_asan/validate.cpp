@@ -88,6 +88,30 @@ int main() {
     EXPECT(capdec_train_state_advance(nullptr, 0.9f, 0.999f, nullptr), CAPDEC_EINVAL);
     EXPECT(capdec_train_state_advance(reinterpret_cast<capdec_train_state*>(a), 1.5f, 0.999f, nullptr), CAPDEC_EINVAL);
     EXPECT(capdec_lstm_step(nullptr, 8, nullptr, 0, nullptr, a, a, a, a, 4, 8, 8, a, 8, a, nullptr, nullptr), CAPDEC_EINVAL);
+    // per-sample contractions and row softmax
+    capdec_bgemm_desc bd{};
+    EXPECT(capdec_bgemm(nullptr, CAPDEC_BGEMM_NT, nullptr), CAPDEC_EINVAL);
+    EXPECT(capdec_bgemm(&bd, CAPDEC_BGEMM_NT, nullptr), CAPDEC_EINVAL);                           // null operands
+    bd.P = a; bd.Q = a; bd.C = a; bd.ldp = 8; bd.ldq = 8; bd.ldc = 8; bd.dense_stride = 32;
+    bd.mult = 1; bd.seg = 4; bd.B = 1; bd.I = 4; bd.J = 4; bd.K = 8; bd.scale = 1.f;
+    EXPECT(capdec_bgemm(&bd, 3, nullptr), CAPDEC_EINVAL);                                         // unknown form
+    bd.K = 6;
+    EXPECT(capdec_bgemm(&bd, CAPDEC_BGEMM_NT, nullptr), CAPDEC_EINVAL);                           // K % 4 != 0
+    bd.K = 8; bd.ldp = 6;
+    EXPECT(capdec_bgemm(&bd, CAPDEC_BGEMM_NT, nullptr), CAPDEC_EALIGN);                           // ldp % 4 != 0
+    bd.ldp = 8; bd.P = una;
+    EXPECT(capdec_bgemm(&bd, CAPDEC_BGEMM_NT, nullptr), CAPDEC_EALIGN);
+    bd.P = a; bd.P2 = a;
+    EXPECT(capdec_bgemm(&bd, CAPDEC_BGEMM_TN, nullptr), CAPDEC_EINVAL);                           // P2 without Q2
+    bd.P2 = nullptr; bd.J = 6;
+    EXPECT(capdec_bgemm(&bd, CAPDEC_BGEMM_NN, nullptr), CAPDEC_EINVAL);                           // J % 4 != 0
+    bd.J = 4; bd.B = 0;
+    EXPECT(capdec_bgemm(&bd, CAPDEC_BGEMM_NN, nullptr), 0);                                       // empty batch: nothing to do
+    EXPECT(capdec_softmax_rows(nullptr, 8, 4, 5, 8, nullptr, 0, 1, nullptr), CAPDEC_EINVAL);
+    EXPECT(capdec_softmax_rows(a, 8, 4, 9, 8, nullptr, 0, 1, nullptr), CAPDEC_EINVAL);            // pad_to < cols
+    EXPECT(capdec_softmax_rows(a, 4, 4, 5, 8, nullptr, 0, 1, nullptr), CAPDEC_EINVAL);            // ld < pad_to
+    EXPECT(capdec_softmax_rows(a, 8, 0, 5, 8, nullptr, 0, 1, nullptr), 0);
+    EXPECT(capdec_softmax_rows_bwd(a, nullptr, 8, 4, 5, 8, 1.f, nullptr, 0, 1, nullptr), CAPDEC_EINVAL);
     EXPECT(capdec_topk_rows(a, 4, 65, 3, a, ai, nullptr), CAPDEC_EINVAL);                          // n > 64
     EXPECT(capdec_topk_rows(a, 4, 9, 0, a, ai, nullptr), CAPDEC_EINVAL);
 
