@@ -256,58 +256,64 @@ def cnn_rnn_variant(device, reps=50):
                     "sample": f"{n} batches of {Br} in 3 s, oracle restatement of the reference loop"}}
 
 
-def train_tokens197_variant(device, steps=6, warmup=2):
-    """Training over 197 ViT tokens of width 768 (S=197): Linear(768,E) per token, 3-layer decoder, loss, backward,
-    Adam."""
+def train_memory_variant(device, steps=6, warmup=2, parts=((197, 768),), layers=3, name="ViT-Attn"):
+    """Training over a per-sample memory made of projected rows: ``parts`` = ((rows, width), ...), each with its own
+    Linear(width, E) (197 ViT tokens of width 768; 64 grid cells of width 2048), concatenated to S rows; decoder of
+    ``layers`` layers, loss, backward (through the projections' weights), Adam."""
     from capdec import autograd as AG
     from capdec import ops
     from capdec.trainer import CaptionTrainer
     from models.vitattn_model import VITAttentionModel
     g = torch.Generator().manual_seed(1234 + 2)
-    Bt, T, Lt, St, Dt = 512, 20, 3, 197, 768
+    Bt, T, Lt = 512, 20, layers
+    St = sum(r for r, _ in parts)
     torch.manual_seed(0)
     m = VITAttentionModel(E, V, H, Lt).to(device).train()
     tr = CaptionTrainer(m, lr=1e-3)
-    w_tok = (torch.randn(E, Dt, generator=g) * Dt ** -0.5).to(device)
-    b_tok = torch.zeros(E, device=device)
-    gw, gb = torch.zeros_like(w_tok), torch.zeros_like(b_tok)
-    mw, vw = torch.zeros(E * Dt + E, device=device), torch.zeros(E * Dt + E, device=device)
-    tokens = torch.randn(Bt * St, Dt, generator=g).to(device)
-    caps = torch.zeros(Bt, T + 1, dtype=torch.long)
-    for b in range(Bt):
-        n = int(torch.randint(8, 20, (1,), generator=g))       # caption body length in [8,19], as in the training leg
-        caps[b, 0] = 1
-        caps[b, 1:1 + n] = torch.randint(4, V, (n,), generator=g)
-        caps[b, 1 + n] = 2
-    caps = caps.to(device)
+    proj = []
+    for rows_i, d_i in parts:
+        w = (torch.randn(E, d_i, generator=g) * d_i ** -0.5).to(device)
+        bias = torch.zeros(E, device=device)
+        proj.append(dict(S=rows_i, D=d_i, w=w, b=bias, gw=torch.zeros_like(w), gb=torch.zeros_like(bias),
+                         mo=torch.zeros(2, E * d_i + E, device=device),
+                         x=torch.randn(Bt * rows_i, d_i, generator=g).to(device)))
+    caps = synthetic_captions(g, Bt, T).to(device)
     ids, tgt = caps[:, :-1].contiguous(), caps[:, 1:].contiguous()
     ragged = AG.ragged_supported(m, St, T, Bt)
     k = [0]
-
     side = torch.cuda.Stream(device=device)
 
     def tstep():
         k[0] += 1
         tr.flat_g.zero_()
-        gw.zero_()
-        gb.zero_()
+        for pr in proj:
+            pr["gw"].zero_()
+            pr["gb"].zero_()
         AG.use_side_stream(side)           # weight-gradient contractions beside the input-gradient chain, as in CaptionTrainer
-        enc = ops.linear(tokens, w_tok, b_tok)
+        encs = [ops.linear(pr["x"], pr["w"], pr["b"]).view(Bt, pr["S"], E) for pr in proj]
+        enc = encs[0] if len(encs) == 1 else torch.cat(encs, 1)
         rg = ops.RaggedRows(ids, tgt, 0) if ragged else None
-        x, tape = AG.tf_forward(m, enc.view(Bt, St, E), ids, m.dropout.p, AG.draw_seed(), ragged=rg)
+        x, tape = AG.tf_forward(m, enc, ids, m.dropout.p, AG.draw_seed(), ragged=rg)
         if rg is not None:
             loss, saved = AG.vocab_loss(m, x, rg.targets_c, rows=rg.rows)
         else:
             loss, saved = AG.vocab_loss(m, x, tgt)
         dx = AG.vocab_loss_bwd(m, x, saved, tr.grads)
         denc = AG.tf_backward(m, tape, dx, tr.grads, need_denc=True)
-        ops.linear_wgrad(denc.view(Bt * St, E), tokens, out=gw)
-        ops.colsum(denc.view(Bt * St, E), gb)
+        off = 0
+        for pr in proj:
+            d = denc[:, off:off + pr["S"]]
+            d = (d if len(proj) == 1 else d.contiguous()).view(Bt * pr["S"], E)
+            off += pr["S"]
+            ops.linear_wgrad(d, pr["x"], out=pr["gw"])
+            ops.colsum(d, pr["gb"])
         AG.join_side_stream()
         AG.use_side_stream(None)
         ops.adam_step(tr.flat_p, tr.flat_g, tr.m, tr.v, 1e-3, k[0])
-        ops.adam_step(w_tok.view(-1), gw.view(-1), mw[:E * Dt], vw[:E * Dt], 1e-3, k[0])
-        ops.adam_step(b_tok, gb, mw[E * Dt:], vw[E * Dt:], 1e-3, k[0])
+        for pr in proj:
+            n = E * pr["D"]
+            ops.adam_step(pr["w"].view(-1), pr["gw"].view(-1), pr["mo"][0, :n], pr["mo"][1, :n], 1e-3, k[0])
+            ops.adam_step(pr["b"], pr["gb"], pr["mo"][0, n:], pr["mo"][1, n:], 1e-3, k[0])
         return loss
 
     for _ in range(warmup):
@@ -322,21 +328,59 @@ def train_tokens197_variant(device, steps=6, warmup=2):
     # every layer): the yardstick of the S=1 legs.  This step does not execute them: the cross-attention contracts the
     # memory against the H*T query rows of a sample instead (autograd.cross_absorbed), and only the live rows R go
     # through the stack, so the count it executes is several times smaller and is what the MFMA fraction is taken of.
-    f_fwd = Lt * (16 * T * E * E + 4 * St * E * E + 4 * T * T * E + 4 * T * St * E) + 2 * T * E * V + 2 * St * Dt * E
+    f_head = sum(2 * r * d * E for r, d in parts)
+    f_fwd = Lt * (16 * T * E * E + 4 * St * E * E + 4 * T * T * E + 4 * T * St * E) + 2 * T * E * V + f_head
     tf = 3.0 * f_fwd * Bt / dt / 1e12
-    lens = (caps[:, 1:] != 0).sum(1)
+    lens = (caps[:, 1:] != 0).sum(1).cpu()
     R, live_sq = int(lens.sum()), int((lens * lens).sum())
     folded = AG.cross_absorbed(St, T, E, H)
     cross_fwd = (8 * R * E * E + 4 * H * R * St * E) if folded else (4 * R * E * E + 4 * Bt * St * E * E + 4 * R * St * E)
     f_exec = 3.0 * (Lt * (12 * R * E * E + cross_fwd + 4 * live_sq * E) + 2 * R * E * V) \
-        + 2.0 * (2 * Bt * St * Dt * E)                     # the token projection has no input gradient
+        + 2.0 * Bt * f_head                                # the memory projections have no input gradient
     tf_exec = f_exec / dt / 1e12
-    return {"workload": f"ViT-Attn training over 197x768 tokens (S=197), B={Bt}, T={T}, L={Lt}, dropout 0.1, Adam; "
-                        "caption bodies of 8-19 tokens (27 % <PAD> tails), decoder rows ragged; cross-attention with the "
-                        "key / value projections folded onto the query side" + ("" if folded else " OFF"),
+    what = " + ".join(f"{r}x{d}" for r, d in parts)
+    return {"workload": f"{name} training over a projected memory of {what} rows (S={St}), B={Bt}, T={T}, L={Lt}, dropout 0.1, "
+                        "Adam; caption bodies of 8-19 tokens (27 % <PAD> tails), decoder rows ragged; cross-attention with "
+                        "the key / value projections folded onto the query side" + ("" if folded else " OFF"),
             "value": Bt / dt, "unit": "samples/s", "ms_per_step": dt * 1e3,
             "reference_formulation_tflops": tf, "executed_tflops": tf_exec,
             "executed_mfma_frac": tf_exec / FP32_MFMA_PEAK_TFLOPS}
+
+
+def train_tokens197_variant(device, steps=6, warmup=2):
+    """BASELINE.json configs[2] as worded: ViT-Attn training over 197 ViT tokens of width 768 (S=197), L=3."""
+    return train_memory_variant(device, steps, warmup, parts=((197, 768),), layers=3, name="ViT-Attn")
+
+
+def decode_memory_variant(device, steps, warmup, parts, layers, name):
+    """Greedy decode (B=1024, len 20) over a per-sample memory of projected rows (see train_memory_variant): the
+    projections, the per-layer key / value projections of the memory and the cached decode loop."""
+    from capdec import engine, ops
+    from models.vitattn_model import VITAttentionModel
+    torch.manual_seed(0)
+    m = VITAttentionModel(E, V, H, layers).to(device).eval()
+    g = torch.Generator().manual_seed(1234 + 4)
+    proj = [dict(S=r, w=(torch.randn(E, d, generator=g) * d ** -0.5).to(device), b=torch.zeros(E, device=device),
+                 x=torch.rand(B * r, d, generator=g).to(device)) for r, d in parts]
+    St = sum(r for r, _ in parts)
+
+    def dstep():
+        with torch.no_grad():
+            encs = [ops.linear(pr["x"], pr["w"], pr["b"]).view(B, pr["S"], E) for pr in proj]
+            enc = encs[0] if len(encs) == 1 else torch.cat(encs, 1)
+            return engine.tf_greedy_ids(m, enc, LEN, 1, 2, to_cpu=True)
+
+    for _ in range(warmup):
+        dstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    what = " + ".join(f"{r}x{d}" for r, d in parts)
+    return {"workload": f"{name} greedy decode over a projected memory of {what} rows (S={St}), B={B}, len {LEN}, L={layers}",
+            "value": B / dt, "unit": "captions/s", "ms_per_step": dt * 1e3}
 
 
 def variants_bench(device, steps=6, warmup=2):
@@ -466,6 +510,12 @@ def variants_bench(device, steps=6, warmup=2):
         "value": Bs / dt, "unit": "samples/s", "ms_per_step": dt * 1e3}
     del sat, grid, feats
     out["train_tokens197"] = train_tokens197_variant(device, steps, warmup)
+    # ---- BASELINE.json configs[3] as worded: 197 ViT tokens + 64 grid cells -> S=261, L=2: training and greedy decode ----
+    torch.cuda.empty_cache()
+    out["cfg4_train_tokens_grid261"] = train_memory_variant(device, steps, warmup, parts=((197, 768), (64, 2048)), layers=2,
+                                                            name="ViTCNN-Attn")
+    torch.cuda.empty_cache()
+    out["cfg4_decode_tokens_grid261"] = decode_memory_variant(device, steps, warmup, ((197, 768), (64, 2048)), 2, "ViTCNN-Attn")
     return out
 
 

@@ -366,8 +366,10 @@ def gemm_layout_groups(groups, layout, rows_dev=None, k_dev=None):
 
 def bgemm(form, P, Q, C, B, seg, mult, seg_off=None, scale=1.0, P2=None, Q2=None, accumulate=False):
     """Per-sample contractions over a ragged batch (capdec_bgemm in capdec.h).  form "nt" / "nn": P, C hold the
-    samples' rows ([rows, K] / [rows, J]), Q is [B*J, K] / [B*K, J]; form "tn": P, Q hold the rows ([rows, I>=..],
-    [rows, J]) and C is [B*I, J].  The per-sample sizes come from the dense operand's shape."""
+    samples' rows ([rows, K] / [rows, J]), Q is [B*J, K] / [B*K, J]; form "tn": P, Q hold the rows ([rows, >= I],
+    [rows, J]) and C is [B*I, J].  The per-sample sizes come from the dense operand's shape.  Sample b owns the rows
+    [seg_off[b]*mult, seg_off[b+1]*mult) (seg_off None: seg*mult rows each); with seg_off the caller guarantees that
+    seg_off[B]*mult does not exceed the rows of P (the offsets live on the device and are not read here)."""
     lib = _lib.load()
     d = _lib.BgemmDesc()
     for t, nm in ((P, "P"), (Q, "Q"), (C, "C")):
@@ -376,19 +378,35 @@ def bgemm(form, P, Q, C, B, seg, mult, seg_off=None, scale=1.0, P2=None, Q2=None
     d.ldp, d.ldq, d.ldc = _row_stride(P, "P"), _row_stride(Q, "Q"), _row_stride(C, "C")
     d.B, d.seg, d.mult, d.scale, d.accumulate = B, seg, mult, scale, 1 if accumulate else 0
     d.seg_off = None if seg_off is None else _chk(seg_off, torch.int32, "seg_off").data_ptr()
+    if B < 1 or (seg_off is not None and seg_off.numel() != B + 1):
+        raise RuntimeError("capdec bgemm: B must be positive and seg_off hold B + 1 offsets")
+    rows = P.shape[0]                     # rows of the ragged operands (every sample's rows lie below this)
+    if seg_off is None and B * seg * mult > rows:
+        raise RuntimeError(f"capdec bgemm: {B} samples of {seg * mult} rows do not fit the {rows} rows of P")
+    dense = C if form == "tn" else Q
+    if dense.shape[0] % B:
+        raise RuntimeError(f"capdec bgemm: the dense operand's {dense.shape[0]} rows are not a multiple of B={B}")
     if form == "nt":
         d.J, d.K, d.I = Q.shape[0] // B, Q.shape[1], 1
+        if P.shape[1] != d.K or C.shape[0] != rows or C.shape[1] < d.J:
+            raise RuntimeError(f"capdec bgemm nt: P {tuple(P.shape)} Q {tuple(Q.shape)} C {tuple(C.shape)}")
         d.dense_stride = d.J * d.ldq
         code = 0
     elif form == "nn":
         d.K, d.J, d.I = Q.shape[0] // B, Q.shape[1], 1
+        if P.shape[1] < (d.K + 3) // 4 * 4 or C.shape[0] != rows or C.shape[1] != d.J:
+            raise RuntimeError(f"capdec bgemm nn: P {tuple(P.shape)} Q {tuple(Q.shape)} C {tuple(C.shape)}")
         d.dense_stride = d.K * d.ldq
         code = 1
     elif form == "tn":
         d.I, d.J, d.K = C.shape[0] // B, C.shape[1], 1
+        if P.shape[1] < (d.I + 3) // 4 * 4 or Q.shape[0] != rows or Q.shape[1] != d.J:
+            raise RuntimeError(f"capdec bgemm tn: P {tuple(P.shape)} Q {tuple(Q.shape)} C {tuple(C.shape)}")
         d.dense_stride = d.I * d.ldc
         code = 2
         if P2 is not None:
+            if Q2 is None or P2.shape != P.shape or Q2.shape != Q.shape:
+                raise RuntimeError("capdec bgemm tn: P2 / Q2 must have the shapes of P / Q")
             if _row_stride(P2, "P2") != d.ldp or _row_stride(Q2, "Q2") != d.ldq:
                 raise RuntimeError("capdec bgemm: P2 / Q2 must have the row strides of P / Q")
             d.P2, d.Q2 = _chk(P2, name="P2").data_ptr(), _chk(Q2, name="Q2").data_ptr()

@@ -243,3 +243,15 @@ def test_host_side_argument_validation_under_address_sanitizer():
     res = subprocess.run([exe], capture_output=True, text=True, timeout=120,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1"))
     assert res.returncode == 0 and "all checks passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_folded_cross_attention_cost_rule():
+    """The folded form of the cross-attention (memory contracted against the H*T query rows) is taken when it costs at
+    most half the multiply-adds of projecting the memory: long memories, few query rows."""
+    from capdec.autograd import cross_absorbed
+    assert cross_absorbed(197, 20, 512, 4) and cross_absorbed(261, 20, 512, 4) and cross_absorbed(1000, 50, 512, 4)
+    assert not cross_absorbed(1, 20, 512, 4) and not cross_absorbed(2, 20, 512, 4) and not cross_absorbed(64, 20, 512, 4)
+    assert not cross_absorbed(197, 200, 512, 4)          # as many query rows as memory rows: projecting is cheaper
+    assert not cross_absorbed(197, 20, 510, 3)           # head width not a multiple of four
+    for S, T, E, H in ((65, 5, 64, 4), (300, 33, 128, 2), (100, 40, 512, 8)):
+        assert cross_absorbed(S, T, E, H) == (2 * T * (H * S + E) <= S * E + T * S)
