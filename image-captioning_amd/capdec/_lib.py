@@ -18,6 +18,7 @@ GEMM_TQ = 4
 GEMM_ATOMIC = 8
 GEMM_SPLITK = 16
 DECODE_NO_S1_SHORTCUT = 1
+DECODE_FOLD_MEMORY = 2
 VOCAB_STATIC_MAX_ELEMS = 1 << 20
 E2BIG = -7
 

@@ -91,7 +91,7 @@ class VocabProbe:
 
 
 def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=False, resolve_dirty=True, probe=None,
-                  to_cpu=True, extra_cap=0):
+                  to_cpu=True, extra_cap=0, fold_memory=False):
     """Greedy decode on the GPU.  enc [B,S,E] fp32.  Returns (ids int64 [B,max_length] padded with -1, lengths
     int32 [B], number of rows that went through the exact path).  ids/lengths are CPU tensors unless
     ``to_cpu=False`` (then they stay on the device, e.g. for a cross-rank gather)."""
@@ -129,7 +129,9 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
                 if nbytes == 0:
                     raise RuntimeError("capdec: unsupported decoder configuration (see capdec.h)")
                 ws = _workspace(nbytes, dev)
-                flags = _lib.DECODE_NO_S1_SHORTCUT if no_s1_shortcut else 0
+                # no_s1_shortcut: the general cross-attention kernels whatever the number of memory rows;
+                # fold_memory: the folded form (taken by itself for long memories) forced for any S >= 3
+                flags = (_lib.DECODE_NO_S1_SHORTCUT if no_s1_shortcut else 0) | (_lib.DECODE_FOLD_MEMORY if fold_memory else 0)
                 _lib.check(lib.capdec_tf_greedy_decode(ctypes.byref(ref.c), enc.data_ptr(), B, S, max_length, sos, eos,
                                                        flags, extra_cap, ws.data_ptr(), ws.numel(), out_ids.data_ptr(),
                                                        out_len.data_ptr(), dirty.data_ptr(),

@@ -85,6 +85,12 @@ int capdec_launch_layernorm_pair_rows(const float* x, const float* gamma1, const
                                       const float* beta2, float eps, int Mcap, int E, float* y, const int32_t* rows_dev,
                                       const int32_t* row_map, int map_div, const float* G, const float* D, const float* c1,
                                       const float* sb, int H, float scale, hipStream_t s);
+// Decode-step attention of Rcap rows over the raw memory of their samples ([B*S][E], E in {64, 128, 256, 512}): qp, ctx
+// [Rcap][H*E] (head h in columns [h*E, (h+1)*E)); see attention_memory_kernel in ops.hip
+inline bool capdec_attention_memory_supported(int E) { return E == 64 || E == 128 || E == 256 || E == 512; }
+int capdec_launch_attention_memory_rows(const float* qp, int64_t ldq, const float* mem, int S, int E, int H, float scale,
+                                        float* ctx, int64_t ldc, int Rcap, const int32_t* row_map, int map_div,
+                                        const int32_t* rows_dev, hipStream_t s);
 int capdec_launch_attention_rows(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
                                  int64_t ldv, int64_t sv, float* out, int64_t ldo, int Rcap, int H, int Tk, int dk,
                                  int causal, const int32_t* ids, int64_t ldid, const int32_t* row_map, int map_div,

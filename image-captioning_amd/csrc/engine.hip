@@ -634,6 +634,41 @@ int pair_memory_constants(const capdec_tf_model* m, const float* ck, const float
     return 0;
 }
 
+// ---- long memories in decode: key / value projections folded into the query and output projections --------------
+// scores_h = ((x1 W_q^T + b_q)_h W_k,h) mem^T / sqrt(dk) = (x1 W1_h^T + b1_h) mem^T / sqrt(dk),  W1_h = W_k,h^T W_q,h  [E,E]
+// block   = sum_h (P_h mem) (W_o,h W_v,h)^T + W_o b_v + b_o = ctx W2^T + b2,  W2[:, h] = W_o[:, h] W_v,h  [E,E] per head
+// (b_k shifts every score of a row equally and drops out of the softmax; b_v passes through because the probabilities
+//  of a row sum to one; transformer.py:21-27,45-60,86).  Weights only: computed once per call, four small launches a
+//  layer.  W1 [L][H*E][E], b1 [L][H*E], W2 [L][E][H*E], b2 [L][E].
+int fold_memory_weights(const capdec_tf_model* m, float* W1, float* b1, float* W2, float* b2, hipStream_t s) {
+    const int E = m->E, H = m->H, dk = E / H;
+    const size_t EE = (size_t)E * E;
+    for (int l = 0; l < m->L; ++l) {
+        const capdec_attn_w& a = m->layers[l].cross_attn;
+        for (int h0 = 0; h0 < H; h0 += 4) {
+            const int n = H - h0 < 4 ? H - h0 : 4;
+            capdec_gemm_group g1[4], gb[4], g2[4];
+            for (int i = 0; i < n; ++i) {
+                const int h = h0 + i;
+                const float* wkh = a.wk + (size_t)h * dk * E;      // rows h*dk.. of W_k: its [k][j] image for this head
+                const float* wqh = a.wq + (size_t)h * dk * E;
+                g1[i] = linear_group(wkh, E, E, wqh, nullptr, E, W1 + (size_t)l * H * EE + (size_t)h * EE, E);
+                g1[i].ldq = E;
+                gb[i] = linear_group(a.bq + h * dk, dk, 1, wkh, nullptr, E, b1 + (size_t)l * H * E + (size_t)h * E, E);
+                gb[i].ldq = E;
+                g2[i] = linear_group(a.wo + h * dk, E, E, a.wv + (size_t)h * dk * E, nullptr, E,
+                                     W2 + (size_t)l * H * EE + (size_t)h * E, (int64_t)H * E);
+                g2[i].ldq = E;
+            }
+            CAPDEC_TRY(capdec_launch_gemm(g1, n, dk, CAPDEC_GEMM_TP | CAPDEC_GEMM_TQ, s));
+            CAPDEC_TRY(capdec_launch_gemm(gb, n, dk, CAPDEC_GEMM_TQ, s));
+            CAPDEC_TRY(capdec_launch_gemm(g2, n, dk, CAPDEC_GEMM_TQ, s));
+        }
+        CAPDEC_TRY(linear(a.bv, E, 1, a.wo, a.bo, E, E, b2 + (size_t)l * E, E, nullptr, 0, 0, s));
+    }
+    return 0;
+}
+
 // ---- decoder stack over a block of rows ------------------------------------------------------
 // Full-prefix form: X [B*T,E] in, X out (post-LN); every position of every sample is recomputed.
 struct FullBufs {
@@ -689,6 +724,8 @@ struct DecodeWs {
     float *ck, *cv;          // [L][B*S][E]
     float *cc;               // [L][B][E]  S == 1: the whole cross-attention block output per sample (S == 2: c1)
     float *pg, *pd, *psb;    // S == 2: [L][B][H][E] x2 and [L][B][H], see pair_memory_constants
+    float *fw1, *fb1, *fw2, *fb2;   // S >= 3: folded cross-attention weights, see fold_memory_weights
+    float *fq, *fc;          // [Mcap][H*E]: folded queries and contexts of a step
     float* pval; int32_t* pidx;
     int32_t *tok, *done, *first_pad;
     int32_t *rowmap;         // [max_len][Mcap]
@@ -715,6 +752,16 @@ static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, 
         d.pg = c.take<float>((size_t)m->L * BE * m->H);
         d.pd = c.take<float>((size_t)m->L * BE * m->H);
         d.psb = c.take<float>((size_t)m->L * B * m->H);
+    }
+    d.fw1 = d.fb1 = d.fw2 = d.fb2 = d.fq = d.fc = nullptr;
+    if (S >= 3 && capdec_attention_memory_supported(m->E)) {
+        const size_t HEE = (size_t)m->H * m->E * m->E;
+        d.fw1 = c.take<float>((size_t)m->L * HEE);
+        d.fb1 = c.take<float>((size_t)m->L * m->H * m->E);
+        d.fw2 = c.take<float>((size_t)m->L * HEE);
+        d.fb2 = c.take<float>((size_t)m->L * m->E);
+        d.fq = c.take<float>(ME * m->H);
+        d.fc = c.take<float>(ME * m->H);
     }
     const size_t nt = (size_t)capdec_vocab_tiles(m->V);
     d.pval = c.take<float>(capdec_part_elems(B, (int)nt));
@@ -843,6 +890,16 @@ static int linear_rows(const float* x, int Mcap, const float* W, const float* b,
     return capdec_launch_gemm(&g, 1, E, flags, s, &ex);
 }
 
+// the same for a [Mcap,K] x [N,K]^T contraction with its own widths
+static int linear_rows_nk(const float* x, int Mcap, const float* W, const float* b, int N, int K, float* C, const float* R,
+                          const int32_t* rows_dev, hipStream_t s) {
+    capdec_gemm_group g = linear_group(x, K, Mcap, W, b, N, C, N, R, N);
+    g.ldq = K;
+    capdec_gemm_extra ex{};
+    ex.rows_dev = rows_dev;
+    return capdec_launch_gemm(&g, 1, K, 0, s, &ex);
+}
+
 int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, int S, int max_len, int sos, int eos,
                             int flags, int extra_cap, void* workspace, size_t workspace_bytes, int64_t* out_ids,
                             int32_t* out_len, int32_t* out_dirty, const capdec_probe* probe, void* stream) {
@@ -863,6 +920,12 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
     const size_t BE = (size_t)B * E;
     const bool s1 = (S == 1) && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT);
     const bool s2 = (S == 2) && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT);
+    // long memories: the raw memory is attended to directly (see fold_memory_weights); measured at B=1024, E=512, L=2,
+    // len 20: 10.9 against 10.8 ms at 64 rows, 11.5 against 12.3 at 96, 14.8 against 20.1 at 261, so from 80 rows on
+    // this beats projecting the memory to keys and values and reading both at every step
+    const bool fold = w.fw1 && ((flags & CAPDEC_DECODE_FOLD_MEMORY) ||
+                                (S >= CAPDEC_DECODE_FOLD_MIN_ROWS && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT)));
+    CAPDEC_REQUIRE(!(flags & CAPDEC_DECODE_FOLD_MEMORY) || fold);      // forced but unavailable (S < 3 or E not built)
 
     hipLaunchKernelGGL(cached_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, w.first_pad, out_ids,
                        out_len, out_dirty, w.rowmap, w.nrows, B, max_len, sos);
@@ -877,6 +940,8 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
             CAPDEC_TRY(linear(enc, E, B, a.wv, a.bv, E, E, w.ao, E, nullptr, 0, 0, s));
             CAPDEC_TRY(linear(w.ao, E, B, a.wo, a.bo, E, E, w.cc + l * BE, E, nullptr, 0, 0, s));
         }
+    } else if (fold) {
+        CAPDEC_TRY(fold_memory_weights(m, w.fw1, w.fb1, w.fw2, w.fb2, s));
     } else {
         CAPDEC_TRY(project_memory(m, enc, B, S, w.ck, w.cv, s));
         // two keys: the block is a per-sample constant plus H logistic gates (w.q / w.ao are free until the first step)
@@ -914,6 +979,17 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
                                                              rows, map, max_len, w.pg + (size_t)l * BE * H,
                                                              w.pd + (size_t)l * BE * H, w.cc + l * BE,
                                                              w.psb + (size_t)l * B * H, H, 1.0f / sqrtf((float)dk), s));
+            } else if (fold) {
+                const size_t HEE = (size_t)H * E * E;
+                CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, Mcap, E, w.x1,
+                                                        rows, s));
+                CAPDEC_TRY(linear_rows_nk(w.x1, Mcap, w.fw1 + l * HEE, w.fb1 + (size_t)l * H * E, H * E, E, w.fq, nullptr,
+                                          rows, s));
+                CAPDEC_TRY(capdec_launch_attention_memory_rows(w.fq, (int64_t)H * E, enc, S, E, H, 1.0f / sqrtf((float)dk),
+                                                               w.fc, (int64_t)H * E, Mcap, map, max_len, rows, s));
+                CAPDEC_TRY(linear_rows_nk(w.fc, Mcap, w.fw2 + l * HEE, w.fb2 + (size_t)l * E, E, H * E, w.y, w.x1, rows, s));
+                CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n2_g, ly.n2_b, 1e-5f, Mcap, E,
+                                                        w.x2, rows, s));
             } else {
                 CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, Mcap, E, w.x1,
                                                         rows, s));

@@ -314,7 +314,8 @@ def test_f5_greedy_random_weights_cached_and_exact():
     for S in (1, 2, 5):
         enc = t(fx[f"a_enc_S{S}"])
         want = unpad(fx[f"a_ids_S{S}"])
-        for kw in ({}, {"exact": True}, {"no_s1_shortcut": True}):
+        # (fold_memory: the long-memory form of the cross-attention, forced here on the fixture's 5-row memory)
+        for kw in ({}, {"exact": True}, {"no_s1_shortcut": True}) + (({"fold_memory": True},) if S >= 3 else ()):
             got, _ = _greedy(dec, enc, 12, **kw)
             check_greedy(got, sd, enc, int(fx["H"]), 12, want_rows=want)
 
@@ -336,6 +337,39 @@ def test_two_memory_rows_closed_form_against_the_oracle_and_the_general_kernels(
     enc2 = torch.cat([enc[:8] * 30.0, enc[8:16, :1].expand(8, 2, 512)], 0).contiguous()
     got2, _ = _greedy(dec, enc2, 12)
     check_greedy(got2, cpu_sd(dec), enc2, 4, 12)
+
+
+@pytest.mark.parametrize("S,B", [(261, 12), (96, 9), (100, 5), (33, 7)])
+def test_long_memory_decode_attends_to_the_raw_memory(S, B):
+    """From 80 memory rows on the cached decoder folds the key / value projections into the query and output
+    projections and reads the raw memory once per step: same tokens as the oracle (near-ties aside) and as the
+    projected form, at the benchmark's widths; forced on a shorter memory too.  Rows that generate <PAD> are re-run
+    through the same kernels."""
+    torch.manual_seed(11)
+    dec = plain_decoder(512, 10000, 4, 2).cuda().eval()
+    g = torch.Generator().manual_seed(S)
+    enc = torch.randn(B, S, 512, generator=g)
+    kw = {} if S >= 80 else {"fold_memory": True}
+    got, _ = _greedy(dec, enc, 10, **kw)
+    check_greedy(got, cpu_sd(dec), enc, 4, 10)
+    projected, _ = _greedy(dec, enc, 10, no_s1_shortcut=True)
+    assert sum(a == b for a, b in zip(got, projected)) >= B - 1
+    with pytest.raises(RuntimeError):                 # nothing to fold with one or two memory rows
+        _greedy(dec, enc[:, :2].contiguous(), 4, fold_memory=True)
+
+
+def test_long_memory_decode_with_generated_pad_rows():
+    fx = load_golden("f5_greedy")
+    sd = sub_sd(fx, "b__sd__")
+    dec = decoder_from_sd(sd, int(fx["H"]))
+    enc = t(fx["b_enc"])
+    if enc.shape[1] < 3:
+        enc = enc[:, :1].expand(-1, 3, -1).contiguous()       # three equal memory rows attend like one
+    want = unpad(fx["b_ids"])
+    got, n_fallback = _greedy(dec, enc, 14, extra_cap=256, fold_memory=True)
+    assert n_fallback == 0
+    check_greedy(got, sd, enc, int(fx["H"]), 14, want_rows=want if t(fx["b_enc"]).shape[1] >= 3 else None)
+    assert sum(0 in row for row in got) >= len(got) // 2          # the fixture's point: most rows emit <PAD>
 
 
 def test_greedy_outputs_packed_on_the_device_and_prebuilt_parameter_struct():
