@@ -921,8 +921,7 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
     const bool s1 = (S == 1) && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT);
     const bool s2 = (S == 2) && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT);
     // long memories: the raw memory is attended to directly (see fold_memory_weights); measured at B=1024, E=512, L=2,
-    // len 20: 10.9 against 10.8 ms at 64 rows, 11.5 against 12.3 at 96, 14.8 against 20.1 at 261, so from 80 rows on
-    // this beats projecting the memory to keys and values and reading both at every step
+    // len 20: 9.7 against 9.9 ms at 48 rows, 10.0 against 10.7 at 64, 10.5 against 12.3 at 96, 12.7 against 20.1 at 261
     const bool fold = w.fw1 && ((flags & CAPDEC_DECODE_FOLD_MEMORY) ||
                                 (S >= CAPDEC_DECODE_FOLD_MIN_ROWS && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT)));
     CAPDEC_REQUIRE(!(flags & CAPDEC_DECODE_FOLD_MEMORY) || fold);      // forced but unavailable (S < 3 or E not built)

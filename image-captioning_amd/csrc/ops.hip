@@ -695,168 +695,176 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
 // ---- decode-step attention over the raw memory (key / value projections folded away) ----------------------------
 // One workgroup per decode row, four heads per pass.  The query of head h is q'_h = (q W_k)_h, E wide (computed by the
 // caller with the folded weight W_k,h^T W_q,h), scores_j = q'_h . mem_j * scale, and the output is the context
-// sum_j p_j mem_j, E wide per head (the caller applies the folded W_o,h W_v,h).  The sample's S memory rows are staged
-// through LDS in chunks of AM_KC rows, read from memory ONCE for all heads and for both products (the projected form
-// reads a K row and a V row per memory row and head group: twice the bytes, plus the projection itself).
-// Wavefront w owns the column quarter [w E/4, (w+1) E/4) of the memory rows for ALL four heads: a first form gave each
-// wavefront one head and the whole row, so every chunk was read from LDS eight times (4 heads x 2 products) and the
-// kernel was LDS-bound at 290 us for 1024 rows x 261 keys; here a chunk is read twice.  Per chunk: partial scores of
-// the quarter for 4 heads x 32 keys (8 lanes per key) -> LDS -> wavefront h adds the four partials of head h and
-// updates its running softmax (maximum, sum, rescale factor) -> LDS -> every wavefront accumulates its columns of the
-// four contexts.
-constexpr int AM_KC = 32, AM_HB = 4;
+// sum_j p_j mem_j, E wide per head (the caller applies the folded W_o,h W_v,h).  The sample's S memory rows are read
+// from memory ONCE for all heads and for both products (the projected form reads a K row and a V row per memory row
+// and head group: twice the bytes, plus the projection itself).
+// No LDS staging and no barriers in the key loop: the workgroup's four wavefronts take the key groups w, w+4, ... (four
+// keys each); a memory row goes straight into registers, a lane owning E/64 of its columns (16-byte slices lane,
+// lane+64: every load instruction covers 1 KiB of one row); the 4 keys x 4 heads partial scores of a group are summed
+// over the lanes with a reduce-scatter (8+4+2+1+2 shuffles: 4.25 per key instead of 24 for sixteen full reductions),
+// after which lane L holds the score of (key, head) = ((L >> 4) & 3, (L >> 2) & 3) and keeps the running maximum and
+// sum of that head; exp-scores and rescale factors go back to all lanes as constant-lane reads.  The next group's
+// rows are in flight while the current one is worked on.  The four partial softmaxes meet once, at the end, in LDS.
+// (Two earlier forms staged 32-row chunks through LDS: a head per wavefront -- LDS-bound, 290 us at 1024 rows x 261 keys --
+//  and a column quarter per wavefront with the softmax through LDS -- four barriers per chunk, 166 us; this one 107 us.)
+constexpr int AM_KG = 4, AM_HB = 4;
 
 template <int E>
-__global__ __launch_bounds__(256) void attention_memory_kernel(const float* __restrict__ qp, int64_t ldq,
-                                                               const float* __restrict__ mem, int S, int H, float scale,
-                                                               float* __restrict__ ctx, int64_t ldc,
-                                                               const int32_t* __restrict__ row_map, int map_div,
-                                                               const int32_t* __restrict__ rows_dev) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int row = blockIdx.x;
+__global__ __launch_bounds__(256, 2) void attention_memory_kernel(const float* __restrict__ qp, int64_t ldq,
+                                                                  const float* __restrict__ mem, int S, int H, float scale,
+                                                                  float* __restrict__ ctx, int64_t ldc,
+                                                                  const int32_t* __restrict__ row_map, int map_div,
+                                                                  const int32_t* __restrict__ rows_dev) {
+    constexpr int NS = E >= 256 ? E / 256 : 1;          // 16-byte slices of a row per lane
+    constexpr int LIVE = E / 4 / NS;                    // lanes that own columns (all 64 from E = 256 on)
+    __shared__ __attribute__((aligned(16))) float mrg[4][AM_HB][4 + NS * 4 * 64];   // per wavefront and head: max, sum, context
+    const int row = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (rows_dev && row >= rows_dev[0]) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int LD = E + 4, NV = E / 4;
-    constexpr int SQ = E / 16;                         // 16-byte slices of a row in one wavefront's column quarter
-    constexpr int PARTS = SQ < 8 ? SQ : 8;             // lanes per key in the score sweep
-    constexpr int NS = SQ / PARTS;                     // slices per lane
-    constexpr int KPS = 64 / PARTS, NSW = AM_KC / KPS; // keys per sweep, sweeps per chunk
-    constexpr int CW = E >= 256 ? E / 256 : 1;         // context columns per lane (of the quarter's E/4)
-    constexpr int CL = E / 4 / CW;                     // lanes that own context columns
-    constexpr int NPF = AM_KC * NV / 256;              // 16-byte slices of a chunk per thread
-    float* Ms = lds;                                   // [AM_KC][LD]
-    float* sp = Ms + AM_KC * LD;                       // [4 waves][AM_HB][AM_KC] partial scores
-    float* pp = sp + 4 * AM_HB * AM_KC;                // [AM_KC][AM_HB] exp-scores
-    float* al = pp + AM_KC * AM_HB;                    // [AM_HB] rescale factors, then 1 / sum
     const int b = (row_map ? row_map[row] : row) / map_div;
     const float* mb = mem + (int64_t)b * S * E;
-    const int part = lane % PARTS, kl = lane / PARTS;
+    const bool own = lane < LIVE;
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int h0 = 0; h0 < H; h0 += AM_HB) {
-        // this lane's slices of the four queries: columns wave * E/4 + 4 * (part + PARTS * i)
         f32x4 q[AM_HB][NS];
 #pragma unroll
         for (int hh = 0; hh < AM_HB; ++hh)
 #pragma unroll
-            for (int i = 0; i < NS; ++i)
-                q[hh][i] = h0 + hh < H ? *reinterpret_cast<const f32x4*>(qp + (int64_t)row * ldq + (int64_t)(h0 + hh) * E +
-                                                                         wave * (E / 4) + 4 * (part + PARTS * i))
-                                       : f32x4{0.f, 0.f, 0.f, 0.f};
-        float m = -INFINITY, l = 0.f;                  // running softmax of head h0 + wave (held by wavefront `wave`)
-        float acc[AM_HB][CW];
+            for (int u = 0; u < NS; ++u)
+                q[hh][u] = (own && h0 + hh < H)
+                               ? *reinterpret_cast<const f32x4*>(qp + (int64_t)row * ldq + (int64_t)(h0 + hh) * E + 4 * (lane + 64 * u))
+                               : zero;
+        f32x4 acc[AM_HB][NS];
 #pragma unroll
         for (int hh = 0; hh < AM_HB; ++hh)
 #pragma unroll
-            for (int u = 0; u < CW; ++u) acc[hh][u] = 0.f;
-        // a chunk is fetched into registers one chunk ahead (in flight while the current chunk is worked on) and
-        // written to LDS once every wavefront is done with the previous one
-        f32x4 pf[NPF];
-        auto fetch = [&](int c0) {
-            const int nk = min(AM_KC, S - c0);
+            for (int u = 0; u < NS; ++u) acc[hh][u] = zero;
+        float m = -INFINITY, l = 0.f;                   // of head (lane >> 2) & 3, over this wavefront's keys
+        f32x4 kv[2][AM_KG][NS];
+        auto fetch = [&](int set, int k0) {
 #pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                const int idx = threadIdx.x + 256 * i;
-                const int r = idx / NV, c = idx - r * NV;
-                const int rr = min(r, nk - 1);         // rows past the end repeat the last one: masked below
-                pf[i] = *reinterpret_cast<const f32x4*>(mb + (int64_t)(c0 + rr) * E + 4 * c);
+            for (int g = 0; g < AM_KG; ++g) {
+                const int k = min(k0 + g, S - 1);       // keys past the end repeat the last one: masked below
+#pragma unroll
+                for (int u = 0; u < NS; ++u)
+                    kv[set][g][u] = own ? *reinterpret_cast<const f32x4*>(mb + (int64_t)k * E + 4 * (lane + 64 * u)) : zero;
             }
         };
-        fetch(0);
-        for (int c0 = 0; c0 < S; c0 += AM_KC) {
-            const int nk = min(AM_KC, S - c0);
-            __syncthreads();                           // the previous chunk (and its scores) are consumed
+        auto work = [&](int set, int k0) {
+            float t[AM_KG * AM_HB];                     // index 4 * key + head
 #pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                const int idx = threadIdx.x + 256 * i;
-                const int r = idx / NV, c = idx - r * NV;
-                *reinterpret_cast<f32x4*>(&Ms[r * LD + 4 * c]) = pf[i];
-            }
-            __syncthreads();
-            if (c0 + AM_KC < S) fetch(c0 + AM_KC);
-            // partial scores over this wavefront's column quarter
-#pragma unroll
-            for (int sw = 0; sw < NSW; ++sw) {
-                const int j = KPS * sw + kl;
-                const float* kr = Ms + j * LD + wave * (E / 4) + 4 * part;
-                float t[AM_HB];
-#pragma unroll
-                for (int hh = 0; hh < AM_HB; ++hh) t[hh] = 0.f;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    const f32x4 kk = *reinterpret_cast<const f32x4*>(kr + 4 * PARTS * i);
-#pragma unroll
-                    for (int hh = 0; hh < AM_HB; ++hh)
-                        t[hh] += q[hh][i][0] * kk[0] + q[hh][i][1] * kk[1] + q[hh][i][2] * kk[2] + q[hh][i][3] * kk[3];
-                }
+            for (int g = 0; g < AM_KG; ++g)
 #pragma unroll
                 for (int hh = 0; hh < AM_HB; ++hh) {
+                    float s = 0.f;
 #pragma unroll
-                    for (int o = 1; o < PARTS; o <<= 1) t[hh] += __shfl_xor(t[hh], o, 64);
+                    for (int u = 0; u < NS; ++u)
+                        s += q[hh][u][0] * kv[set][g][u][0] + q[hh][u][1] * kv[set][g][u][1] + q[hh][u][2] * kv[set][g][u][2] +
+                             q[hh][u][3] * kv[set][g][u][3];
+                    t[4 * g + hh] = s;
                 }
-                if (part < AM_HB) {
-                    // lane `part` of the key's group stores head `part`
-                    float v = t[0];
-                    if (part == 1) v = t[1];
-                    if (part == 2) v = t[2];
-                    if (part == 3) v = t[3];
-                    sp[(wave * AM_HB + part) * AM_KC + j] = v;
-                }
+            // reduce-scatter: after the stage with mask M a lane keeps the half of its values selected by its bit M
+            float a8[8], a4[4], a2[2], a1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float send = b5 ? t[i] : t[i + 8];
+                a8[i] = (b5 ? t[i + 8] : t[i]) + __shfl_xor(send, 32, 64);
             }
-            __syncthreads();
-            // wavefront `wave` finishes head h0 + wave: one key per lane
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float send = b4 ? a8[i] : a8[i + 4];
+                a4[i] = (b4 ? a8[i + 4] : a8[i]) + __shfl_xor(send, 16, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float send = b3 ? a4[i] : a4[i + 2];
+                a2[i] = (b3 ? a4[i + 2] : a4[i]) + __shfl_xor(send, 8, 64);
+            }
             {
-                float sc = -INFINITY;
-                if (lane < AM_KC && lane < nk)
-                    sc = ((sp[(0 * AM_HB + wave) * AM_KC + lane] + sp[(1 * AM_HB + wave) * AM_KC + lane]) +
-                          (sp[(2 * AM_HB + wave) * AM_KC + lane] + sp[(3 * AM_HB + wave) * AM_KC + lane])) * scale;
-                const float mnew = fmaxf(m, wave_max(sc));
-                const float e = expf(sc - mnew);           // 0 for the lanes without a key
-                const float alpha = expf(m - mnew);        // 0 on the first chunk
-                l = l * alpha + wave_sum(e);
-                m = mnew;
-                if (lane < AM_KC) pp[lane * AM_HB + wave] = e;
-                if (lane == 0) al[wave] = alpha;
+                const float send = b2 ? a2[0] : a2[1];
+                a1 = (b2 ? a2[1] : a2[0]) + __shfl_xor(send, 4, 64);
             }
-            __syncthreads();
-            // contexts: this lane's columns of the quarter, four heads
-            if (lane < CL) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(al);
-#pragma unroll
-                for (int hh = 0; hh < AM_HB; ++hh)
-#pragma unroll
-                    for (int u = 0; u < CW; ++u) acc[hh][u] *= a4[hh];
-                const float* col = Ms + wave * (E / 4) + CW * lane;
-#pragma unroll 8
-                for (int j = 0; j < AM_KC; ++j) {          // all rows: the exp-scores past the end are zero
-                    const f32x4 p4 = *reinterpret_cast<const f32x4*>(pp + j * AM_HB);
-                    float v[CW];
-                    if (CW == 2) {
-                        const float2 t2 = *reinterpret_cast<const float2*>(col + j * LD);
-                        v[0] = t2.x;
-                        v[CW - 1] = t2.y;
-                    } else {
-                        v[0] = col[j * LD];
-                    }
-#pragma unroll
-                    for (int hh = 0; hh < AM_HB; ++hh)
-#pragma unroll
-                        for (int u = 0; u < CW; ++u) acc[hh][u] += v[u] * p4[hh];
-                }
-            }
-        }
-        __syncthreads();
-        if (lane == 0) al[wave] = 1.0f / l;
-        __syncthreads();
-        if (lane < CL) {
-            const f32x4 inv = *reinterpret_cast<const f32x4*>(al);
+            a1 += __shfl_xor(a1, 2, 64);
+            a1 += __shfl_xor(a1, 1, 64);
+            // this lane: value index 8 b5 + 4 b4 + 2 b3 + b2 = 4 key + head
+            const int g_mine = (b5 ? 2 : 0) + (b4 ? 1 : 0);
+            const float sc = k0 + g_mine < S ? a1 * scale : -INFINITY;
+            float gm = sc;                              // maximum over the group's keys of this lane's head
+            gm = fmaxf(gm, __shfl_xor(gm, 16, 64));
+            gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
+            const float mnew = fmaxf(m, gm);            // finite: a group's first key exists
+            const float e = expf(sc - mnew);
+            const float alpha = expf(m - mnew);         // 0 on the first group
+            float es = e;
+            es += __shfl_xor(es, 16, 64);
+            es += __shfl_xor(es, 32, 64);
+            l = l * alpha + es;
+            m = mnew;
 #pragma unroll
             for (int hh = 0; hh < AM_HB; ++hh) {
-                if (h0 + hh >= H) break;
-                float* dst = ctx + (int64_t)row * ldc + (int64_t)(h0 + hh) * E + wave * (E / 4) + CW * lane;
+                const float ah = __shfl(alpha, 4 * hh, 64);       // head hh: the lanes with (lane >> 2) & 3 == hh
 #pragma unroll
-                for (int u = 0; u < CW; ++u) dst[u] = acc[hh][u] * inv[hh];
+                for (int u = 0; u < NS; ++u) acc[hh][u] *= ah;
+            }
+#pragma unroll
+            for (int g = 0; g < AM_KG; ++g)
+#pragma unroll
+                for (int hh = 0; hh < AM_HB; ++hh) {
+                    const float p = __shfl(e, 4 * (4 * g + hh), 64);
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) acc[hh][u] += kv[set][g][u] * p;
+                }
+        };
+        const int stride = 4 * AM_KG;
+        int k0 = wave * AM_KG;
+        if (k0 < S) fetch(0, k0);
+        while (k0 < S) {
+            if (k0 + stride < S) fetch(1, k0 + stride);
+            work(0, k0);
+            k0 += stride;
+            if (k0 >= S) break;
+            if (k0 + stride < S) fetch(0, k0 + stride);
+            work(1, k0);
+            k0 += stride;
+        }
+        // the four wavefronts' partial softmaxes meet in LDS; wavefront w finishes head h0 + w
+#pragma unroll
+        for (int hh = 0; hh < AM_HB; ++hh) {
+            float* dst = &mrg[wave][hh][0];
+            const float mh = __shfl(m, 4 * hh, 64), lh = __shfl(l, 4 * hh, 64);
+            if (lane == 0) {
+                dst[0] = mh;
+                dst[1] = lh;
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) *reinterpret_cast<f32x4*>(dst + 4 + 4 * (lane + 64 * u)) = acc[hh][u];
+        }
+        __syncthreads();
+        {
+            const int hh = wave;
+            float mm = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) mm = fmaxf(mm, mrg[w][hh][0]);
+            float lt = 0.f;
+            f32x4 o[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) o[u] = zero;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float mw = mrg[w][hh][0];
+                const float f = mw == -INFINITY ? 0.f : expf(mw - mm);      // a wavefront without keys (S < 16)
+                lt += mrg[w][hh][1] * f;
+#pragma unroll
+                for (int u = 0; u < NS; ++u) o[u] += *reinterpret_cast<const f32x4*>(&mrg[w][hh][4 + 4 * (lane + 64 * u)]) * f;
+            }
+            if (own && h0 + hh < H) {
+                const float inv = 1.0f / lt;
+#pragma unroll
+                for (int u = 0; u < NS; ++u)
+                    *reinterpret_cast<f32x4*>(ctx + (int64_t)row * ldc + (int64_t)(h0 + hh) * E + 4 * (lane + 64 * u)) = o[u] * inv;
             }
         }
-        __syncthreads();                               // al is reused by the next pass
+        __syncthreads();                                // mrg is reused by the next pass
     }
 }
 
@@ -980,25 +988,16 @@ int capdec_launch_attention_memory_rows(const float* qp, int64_t ldq, const floa
     CAPDEC_REQUIRE(qp && mem && ctx && S >= 1 && H >= 1 && map_div >= 1 && capdec_attention_memory_supported(E));
     CAPDEC_REQUIRE(ldq >= (int64_t)H * E && ldc >= (int64_t)H * E && ldq % 4 == 0 && ldc % 4 == 0);
     if (Rcap == 0) return 0;
-    const size_t smem = ((size_t)AM_KC * (E + 4) + 4 * AM_HB * AM_KC + AM_KC * AM_HB + 4) * sizeof(float);
-    bool ok = true;
 #define CAPDEC_CALL(E_)                                                                                              \
-    {                                                                                                                \
-        static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_memory_kernel<E_>),    \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) == hipSuccess; \
-        ok = ready;                                                                                                  \
-        if (ready)                                                                                                   \
-            hipLaunchKernelGGL(attention_memory_kernel<E_>, dim3(Rcap), dim3(256), smem, s, qp, ldq, mem, S, H, scale, ctx, \
-                               ldc, row_map, map_div, rows_dev);                                                     \
-    }
+    hipLaunchKernelGGL(attention_memory_kernel<E_>, dim3(Rcap), dim3(256), 0, s, qp, ldq, mem, S, H, scale, ctx, ldc,    \
+                       row_map, map_div, rows_dev)
     switch (E) {
-        case 64: CAPDEC_CALL(64) break;
-        case 128: CAPDEC_CALL(128) break;
-        case 256: CAPDEC_CALL(256) break;
-        default: CAPDEC_CALL(512) break;
+        case 64: CAPDEC_CALL(64); break;
+        case 128: CAPDEC_CALL(128); break;
+        case 256: CAPDEC_CALL(256); break;
+        default: CAPDEC_CALL(512); break;
     }
 #undef CAPDEC_CALL
-    if (!ok) return CAPDEC_EINVAL;
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

@@ -438,7 +438,7 @@ int capdec_event_elapsed_ms(void* begin, void* end, float* ms);
 #define CAPDEC_DECODE_FOLD_MEMORY 2      /* S >= 3: attend to the raw memory with the key / value projections folded into
                                             the query and output projections (the form taken by itself from
                                             CAPDEC_DECODE_FOLD_MIN_ROWS memory rows on; E in {64,128,256,512}) */
-#define CAPDEC_DECODE_FOLD_MIN_ROWS 80
+#define CAPDEC_DECODE_FOLD_MIN_ROWS 48
 #define CAPDEC_DECODE_NO_S1_SHORTCUT 1   /* run the general cross-attention kernels even when S == 1 or S == 2 (the
                                             closed forms: one key -> the block is a per-sample constant; two keys ->
                                             a per-sample constant plus one logistic gate per head) */

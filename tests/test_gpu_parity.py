@@ -341,7 +341,7 @@ def test_two_memory_rows_closed_form_against_the_oracle_and_the_general_kernels(
 
 @pytest.mark.parametrize("S,B", [(261, 12), (96, 9), (100, 5), (33, 7)])
 def test_long_memory_decode_attends_to_the_raw_memory(S, B):
-    """From 80 memory rows on the cached decoder folds the key / value projections into the query and output
+    """From 48 memory rows on the cached decoder folds the key / value projections into the query and output
     projections and reads the raw memory once per step: same tokens as the oracle (near-ties aside) and as the
     projected form, at the benchmark's widths; forced on a shorter memory too.  Rows that generate <PAD> are re-run
     through the same kernels."""
@@ -349,7 +349,7 @@ def test_long_memory_decode_attends_to_the_raw_memory(S, B):
     dec = plain_decoder(512, 10000, 4, 2).cuda().eval()
     g = torch.Generator().manual_seed(S)
     enc = torch.randn(B, S, 512, generator=g)
-    kw = {} if S >= 80 else {"fold_memory": True}
+    kw = {} if S >= 48 else {"fold_memory": True}
     got, _ = _greedy(dec, enc, 10, **kw)
     check_greedy(got, cpu_sd(dec), enc, 4, 10)
     projected, _ = _greedy(dec, enc, 10, no_s1_shortcut=True)

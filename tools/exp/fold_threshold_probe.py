@@ -29,7 +29,7 @@ def timeit(enc, **kw):
     return (time.perf_counter() - t0) / 4 * 1e3
 
 
-for S in (16, 32, 48, 64, 96, 128, 197, 261):
+for S in [int(x) for x in os.environ.get("PROBE_S", "16,32,48,64,96,128,197,261").split(",")]:
     enc = torch.randn(B, S, E, generator=g).to(dev)
     a = timeit(enc, no_s1_shortcut=True)
     b = timeit(enc, fold_memory=True)
