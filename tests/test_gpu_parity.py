@@ -372,6 +372,22 @@ def test_long_memory_decode_with_generated_pad_rows():
     assert sum(0 in row for row in got) >= len(got) // 2          # the fixture's point: most rows emit <PAD>
 
 
+@pytest.mark.parametrize("S", [1, 2, 64, 261])
+def test_greedy_decode_is_bit_identical_from_run_to_run(S):
+    """No kernel of the decode path adds floating-point numbers in an order that depends on timing (no float atomics):
+    the same batch decoded three times gives the same tokens and lengths, for every form of the cross-attention (one
+    memory row, two, a feature grid, a long token memory)."""
+    from capdec.engine import tf_greedy_ids
+    torch.manual_seed(3)
+    dec = plain_decoder(512, 10000, 4, 2).cuda().eval()
+    g = torch.Generator().manual_seed(100 + S)
+    enc = torch.randn(96, S, 512, generator=g).cuda()
+    first = tf_greedy_ids(dec, enc, 20, R.SOS, R.EOS)
+    for _ in range(2):
+        again = tf_greedy_ids(dec, enc, 20, R.SOS, R.EOS)
+        assert torch.equal(again[0], first[0]) and torch.equal(again[1], first[1])
+
+
 def test_greedy_outputs_packed_on_the_device_and_prebuilt_parameter_struct():
     """ids, lengths and flags share one device allocation: the host copies (one pinned transfer), the device views
     (to_cpu=False, what a cross-rank gather takes) and a call through a parameter struct built once must agree."""
