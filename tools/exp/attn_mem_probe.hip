@@ -1,4 +1,5 @@
-// Standalone timing of attention_memory_kernel (copied from csrc/ops.hip) with parts knocked out:
+// Standalone timing of the LDS-staged form of the decode attention over the raw memory (a column quarter per wavefront,
+// all four heads; superseded in csrc/ops.hip by the register form of attn_mem_probe3.hip) with parts knocked out:
 // KNOCK bit 0: one slice of the score sweep only; bit 1: one key of the context sweep only; bit 2: no global fetches.
 #include <hip/hip_runtime.h>
 #include <cstdio>
