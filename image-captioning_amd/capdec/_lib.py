@@ -97,6 +97,10 @@ _SIGNATURES = {
     "capdec_colsum": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
     "capdec_colsum_rows": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P]),
     "capdec_bgemm": (c_int, [POINTER(BgemmDesc), c_int, _P]),
+    "capdec_pair_diff": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "capdec_pair_diff_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "capdec_pair_gate_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "capdec_pair_gate_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P]),
     "capdec_softmax_rows": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "capdec_softmax_rows_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_float, _P, c_int, c_int, _P]),
     "capdec_softmax_nll_grad": (c_int, [_P, c_int64, _P, c_int, c_int, c_int64, _P, _P, _P, _P]),

@@ -195,7 +195,64 @@ def _cross_absorbed_bwd(t, c, ca, pre, d_ao2, grads, rows, denc, first=False):
     return dq2
 
 
-def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, seed_dev=None, absorb_cross=None):
+def _pair_constants(t, ca):
+    """The per-sample constants of a cross-attention over two memory rows (capdec_pair_gate_fwd in capdec.h): B rows of
+    work that depends on the memory only.  Returns a Tape with kv2 [2, B*2, E], dk, dv [B, E], sb [B, H], G, D
+    [B, H, E], c1 [B, E]."""
+    B, E, H = t.B, t.E, t.H
+    dk = E // H
+    dev = t.enc.device
+    pc = Tape()
+    pc.kv2 = torch.empty((2, B * 2, E), device=dev, dtype=torch.float32)
+    ops.gemm_groups([dict(P=t.enc, Q=ca.W_k.weight, C=pc.kv2[0], bias_j=ca.W_k.bias),
+                     dict(P=t.enc, Q=ca.W_v.weight, C=pc.kv2[1], bias_j=ca.W_v.bias)], E)
+    pc.dk, pc.dv, pc.sb = ops.pair_diff(pc.kv2[0], pc.kv2[1], ca.W_q.bias, H)
+    pc.G = torch.empty((B, H, E), device=dev, dtype=torch.float32)
+    pc.D = torch.empty((B, H, E), device=dev, dtype=torch.float32)
+    g_heads, d_heads = _heads(pc.G.view(B, H * E), H, E), _heads(pc.D.view(B, H * E), H, E)
+    wq, wo = ca.W_q.weight, ca.W_o.weight
+    for h0 in range(0, H, 4):
+        hs = range(h0, min(h0 + 4, H))
+        ops.gemm_layout_groups([dict(P=pc.dk[:, h * dk:(h + 1) * dk], Q=wq[h * dk:(h + 1) * dk], C=g_heads[h]) for h in hs],
+                               "nn")
+        ops.gemm_layout_groups([dict(P=pc.dv[:, h * dk:(h + 1) * dk], Q=wo[:, h * dk:(h + 1) * dk], C=d_heads[h]) for h in hs],
+                               "nt")
+    pc.v1 = pc.kv2[1].view(B, 2 * E)[:, E:]                       # the second memory row's values, [B, E] with stride 2E
+    pc.c1 = ops.linear(pc.v1, wo, ca.W_o.bias)
+    return pc
+
+
+def _pair_constants_bwd(t, c, ca, pre, grads, dG, dD, dc1, dsb, denc):
+    """Backward of ``_pair_constants`` given the gradients of G, D, c1, sb: fills the W_q / W_k / W_v gradients and the
+    weight part of W_o's, adds the memory's gradient onto ``denc`` (when not None)."""
+    B, E, H = t.B, t.E, t.H
+    dk = E // H
+    pc = c.pc
+    dev = dG.device
+    wq, wo = ca.W_q.weight, ca.W_o.weight
+    g_wq, g_wo = _new(grads, pre + "cross_attn.W_q.weight", wq), _new(grads, pre + "cross_attn.W_o.weight", wo)
+    g_bq = _new(grads, pre + "cross_attn.W_q.bias", ca.W_q.bias)
+    _new(grads, pre + "cross_attn.W_k.bias", ca.W_k.bias)          # exactly zero: b_k cancels in k0 - k1
+    dg_heads, dd_heads = _heads(dG.view(B, H * E), H, E), _heads(dD.view(B, H * E), H, E)
+    ops.linear_wgrad(dc1, pc.v1, out=g_wo)
+    d_v1 = ops.linear_dgrad(dc1, wo)
+    ddk = torch.empty((B, E), device=dev, dtype=torch.float32)
+    ddv = torch.empty((B, E), device=dev, dtype=torch.float32)
+    for h0 in range(0, H, 4):
+        hs = range(h0, min(h0 + 4, H))
+        sl = {h: slice(h * dk, (h + 1) * dk) for h in hs}
+        ops.gemm_layout_groups([dict(P=dd_heads[h], Q=pc.dv[:, sl[h]], C=g_wo[:, sl[h]]) for h in hs], "tn")
+        ops.gemm_layout_groups([dict(P=pc.dk[:, sl[h]], Q=dg_heads[h], C=g_wq[sl[h]]) for h in hs], "tn")
+        ops.gemm_layout_groups([dict(P=dd_heads[h], Q=wo[:, sl[h]], C=ddv[:, sl[h]]) for h in hs], "nn")
+        ops.gemm_layout_groups([dict(P=dg_heads[h], Q=wq[sl[h]], C=ddk[:, sl[h]]) for h in hs], "nt")
+    dk2, dv2, qb = ops.pair_diff_bwd(ddk, ddv, dsb, d_v1, ca.W_q.bias, pc.dk, H)
+    ops.colsum(qb, g_bq)
+    _lin_bwd(grads, pre + "cross_attn.W_k", ca.W_k, dk2, t.enc, need_dx=denc is not None, accum=denc, bias_done=True)
+    _lin_bwd(grads, pre + "cross_attn.W_v", ca.W_v, dv2, t.enc, need_dx=denc is not None, accum=denc)
+
+
+def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, seed_dev=None, absorb_cross=None,
+               pair_cross=None):
     """Teacher-forced decoder stack (reference transformer.py:125-132) keeping what the backward needs.
     enc [B,S,E] fp32, ids [B,T] int64.  Returns (x [B*T,E] post-LN output of the last layer, tape).
 
@@ -205,14 +262,17 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, se
     seed_dev (int64 device tensor, optional): its first element is added to ``seed`` by every kernel that draws a mask
     (a step captured in a HIP graph keeps ``seed`` for ever; the device value changes from replay to replay).
     absorb_cross: None = decide by ``cross_absorbed`` (long memories, few query rows); True / False force the form of
-    the cross-attention sub-layer (the two forms differ only in the order of the floating-point sums)."""
+    the cross-attention sub-layer (the two forms differ only in the order of the floating-point sums).
+    pair_cross: None = memories of exactly two rows take the logistic closed form (``_pair_constants``); False keeps
+    them on the general kernels."""
     B, S, E = enc.shape
     T = ids.shape[1]
     M, H = B * T, dec.num_heads
     t = Tape()
     t.B, t.S, t.T, t.E, t.H, t.p, t.seed, t.seed_dev = B, S, T, E, H, p, seed, seed_dev
     t.shortcut = S == 1 and single_row_shortcut
-    t.absorbed = (not t.shortcut) and absorb_cross is not False and (absorb_cross or cross_absorbed(S, T, E, H))
+    t.pair = S == 2 and pair_cross is not False and not absorb_cross and E % (4 * H) == 0 and E <= 1024
+    t.absorbed = not (t.shortcut or t.pair) and absorb_cross is not False and (absorb_cross or cross_absorbed(S, T, E, H))
     t.ids = ids.contiguous()
     t.ids32 = t.ids.to(torch.int32)
     t.enc = enc.reshape(B * S, E)
@@ -243,6 +303,18 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, se
                 v2 = ops.linear(t.enc, ca.W_v.weight, ca.W_v.bias)
                 pre_cc.append((v2, ops.linear(v2, ca.W_o.weight, ca.W_o.bias)))
         t.enc.record_stream(_side())
+    pre_pc = None
+    if t.pair and _side() is not None:
+        # likewise the constants of the two-row closed form
+        side = _side()
+        side.wait_stream(torch.cuda.current_stream())
+        use_side_stream(None)
+        try:
+            with torch.cuda.stream(side):
+                pre_pc = [_pair_constants(t, ly.cross_attn) for ly in dec.decoder_layers]
+        finally:
+            use_side_stream(side)
+        t.enc.record_stream(side)
     for l, ly in enumerate(dec.decoder_layers):
         c = Tape()
         sd = seed + (3 * l + 1) * _SITE
@@ -275,6 +347,19 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, se
                                                              sd + _SITE, x_div=T, rows_dev=rows,
                                                              x_map=None if ragged is None else ragged.sample,
                                                              seed_dev=seed_dev)
+        elif t.pair:
+            if pre_pc is not None:
+                if l == 0:
+                    torch.cuda.current_stream().wait_stream(_side())
+                c.pc = pre_pc[l]
+                for tn in (c.pc.G, c.pc.D, c.pc.c1, c.pc.sb):
+                    tn.record_stream(torch.cuda.current_stream())
+            else:
+                c.pc = _pair_constants(t, ca)
+            a2, c.p2 = ops.pair_gate_fwd(c.x1, c.pc.G, c.pc.D, c.pc.c1, c.pc.sb, H, (E // H) ** -0.5, T,
+                                         sample=None if ragged is None else ragged.sample, rows_dev=rows)
+            c.x2, c.s2, c.m2, c.r2 = ops.add_layernorm_train(a2, c.x1, ly.norm2.weight, ly.norm2.bias, p, sd + _SITE,
+                                                             rows_dev=rows, seed_dev=seed_dev)
         else:
             c.q2 = ops.linear(c.x1, ca.W_q.weight, ca.W_q.bias, rows_dev=rows)
             if t.absorbed:
@@ -355,6 +440,24 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
             for n, prm in (("W_q.weight", ca.W_q.weight), ("W_q.bias", ca.W_q.bias), ("W_k.weight", ca.W_k.weight),
                            ("W_k.bias", ca.W_k.bias)):
                 _new(grads, pre + "cross_attn." + n, prm)                              # exactly zero
+        elif t.pair:
+            dG, dD, dc1, dsb = ops.pair_gate_bwd(d_a2, c.x1, c.p2, c.pc.G, c.pc.D, B, T, H, (E // H) ** -0.5, d_x1,
+                                                 seg_off=None if rg is None else rg.seq_off)
+            side = _side()
+            if side is not None:
+                # B rows of work that nothing on the main chain waits for
+                side.wait_stream(torch.cuda.current_stream())
+                use_side_stream(None)
+                try:
+                    with torch.cuda.stream(side):
+                        _pair_constants_bwd(t, c, ca, pre, grads, dG, dD, dc1, dsb, denc)
+                finally:
+                    use_side_stream(side)
+                for tn in (dG, dD, dc1, dsb, t.enc) + ((denc,) if denc is not None else ()):
+                    tn.record_stream(side)
+                side_used = True
+            else:
+                _pair_constants_bwd(t, c, ca, pre, grads, dG, dD, dc1, dsb, denc)
         else:
             d_ao2 = _lin_bwd(grads, pre + "cross_attn.W_o", ca.W_o, d_a2, c.ao2, bias_done=True, rows=rows)
             if t.absorbed:

@@ -416,6 +416,70 @@ def bgemm(form, P, Q, C, B, seg, mult, seg_off=None, scale=1.0, P2=None, Q2=None
     return C
 
 
+def pair_diff(k2, v2, bq, H):
+    """k2, v2 [B*2, E] (a sample's two projected memory rows) -> dK = k0 - k1, dV = v0 - v1 [B, E], sb [B, H] = b_q,h . dK_h"""
+    lib = _lib.load()
+    B, E = k2.shape[0] // 2, k2.shape[1]
+    dk = torch.empty((B, E), device=k2.device, dtype=torch.float32)
+    dv = torch.empty_like(dk)
+    sb = torch.empty((B, H), device=k2.device, dtype=torch.float32)
+    if not (k2.is_contiguous() and v2.is_contiguous()):
+        raise RuntimeError("capdec pair_diff: k2, v2 must be contiguous")
+    _lib.check(lib.capdec_pair_diff(_chk(k2).data_ptr(), _chk(v2).data_ptr(), _chk(bq).data_ptr(), B, E, H, dk.data_ptr(),
+                                    dv.data_ptr(), sb.data_ptr(), _stream()), "capdec_pair_diff")
+    return dk, dv, sb
+
+
+def pair_diff_bwd(ddk, ddv, dsb, dv1, bq, dk, H):
+    """Backward of ``pair_diff``: -> dk2, dv2 [B*2, E] and qb [B, E] (its column sum is the gradient of b_q)."""
+    lib = _lib.load()
+    B, E = ddk.shape
+    dk2 = torch.empty((2 * B, E), device=ddk.device, dtype=torch.float32)
+    dv2 = torch.empty_like(dk2)
+    qb = torch.empty((B, E), device=ddk.device, dtype=torch.float32)
+    for t_ in (ddk, ddv, dsb, dv1, dk):
+        if not _chk(t_).is_contiguous():
+            raise RuntimeError("capdec pair_diff_bwd: operands must be contiguous")
+    _lib.check(lib.capdec_pair_diff_bwd(ddk.data_ptr(), ddv.data_ptr(), dsb.data_ptr(), dv1.data_ptr(), _chk(bq).data_ptr(),
+                                        dk.data_ptr(), B, E, H, dk2.data_ptr(), dv2.data_ptr(), qb.data_ptr(), _stream()),
+               "capdec_pair_diff_bwd")
+    return dk2, dv2, qb
+
+
+def pair_gate_fwd(x1, G, D, c1, sb, H, scale, T, sample=None, rows_dev=None):
+    """a2 = c1[b] + sum_h sigmoid((x1 . G[b,h] + sb[b,h]) * scale) D[b,h] per row; returns (a2 [M,E], p [M,H])."""
+    lib = _lib.load()
+    M, E = x1.shape
+    a2 = torch.empty((M, E), device=x1.device, dtype=torch.float32)
+    p = torch.zeros((M, H), device=x1.device, dtype=torch.float32)
+    for t_ in (x1, G, D, c1, sb):
+        if not _chk(t_).is_contiguous():
+            raise RuntimeError("capdec pair_gate_fwd: operands must be contiguous")
+    _lib.check(lib.capdec_pair_gate_fwd(x1.data_ptr(), G.data_ptr(), D.data_ptr(), c1.data_ptr(), sb.data_ptr(),
+                                        None if sample is None else _chk(sample, torch.int32, "sample").data_ptr(), T, M, E, H,
+                                        scale, a2.data_ptr(), p.data_ptr(), _ptr(rows_dev), _stream()), "capdec_pair_gate_fwd")
+    return a2, p
+
+
+def pair_gate_bwd(d_a2, x1, p, G, D, B, T, H, scale, d_x1, seg_off=None):
+    """Backward of ``pair_gate_fwd``: adds the rows' input gradient onto d_x1 (in place); returns (dG, dD [B,H,E],
+    dc1 [B,E], dsb [B,H])."""
+    lib = _lib.load()
+    E = x1.shape[1]
+    dG = torch.empty((B, H, E), device=x1.device, dtype=torch.float32)
+    dD = torch.empty_like(dG)
+    dc1 = torch.empty((B, E), device=x1.device, dtype=torch.float32)
+    dsb = torch.empty((B, H), device=x1.device, dtype=torch.float32)
+    for t_ in (d_a2, x1, p, G, D, d_x1):
+        if not _chk(t_).is_contiguous():
+            raise RuntimeError("capdec pair_gate_bwd: operands must be contiguous")
+    _lib.check(lib.capdec_pair_gate_bwd(d_a2.data_ptr(), x1.data_ptr(), p.data_ptr(), G.data_ptr(), D.data_ptr(),
+                                        None if seg_off is None else _chk(seg_off, torch.int32, "seg_off").data_ptr(), B, T, E,
+                                        H, scale, d_x1.data_ptr(), dG.data_ptr(), dD.data_ptr(), dc1.data_ptr(),
+                                        dsb.data_ptr(), _stream()), "capdec_pair_gate_bwd")
+    return dG, dD, dc1, dsb
+
+
 def softmax_rows_(s, cols, live=None, live_idx=0, mult=1):
     """In place: every row of s [rows, ld] becomes softmax(row[:cols]), zeros from there to the row's end.  live: int32
     device array; only the first live[live_idx]*mult rows are touched."""

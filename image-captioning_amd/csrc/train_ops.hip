@@ -286,6 +286,222 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
+// ---- cross-attention over exactly two memory rows, training form ------------------------------------------------------
+// The softmax over two keys is a logistic function of the score difference.  With dK = k0 - k1, dV = v0 - v1 (the
+// projected memory rows of a sample) the block's output for a row x1 of sample b is
+//     a2 = c1[b] + sum_h p_h D[b,h],   p_h = sigmoid((x1 . G[b,h] + sb[b,h]) * scale),
+//     G[b,h] = W_q,h^T dK_h,  sb[b,h] = b_q,h . dK_h,  D[b,h] = W_o[:,h] dV_h,  c1[b] = W_o v1 + b_o
+// (transformer.py:21-27,45-60,86 with Tk = 2): H dot products and H scaled vector additions per row instead of two
+// E x E contractions over all rows and an attention launch.  Everything with a [b] is B rows of work.
+// Forward: one wavefront per row.  sample: row -> sample (nullable: row / T).
+template <int NV>
+__global__ __launch_bounds__(256) void pair_gate_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ G,
+                                                            const float* __restrict__ D, const float* __restrict__ c1,
+                                                            const float* __restrict__ sb, const int32_t* __restrict__ sample,
+                                                            int T, int M, int E, int H, float scale,
+                                                            float* __restrict__ a2, float* __restrict__ p_out,
+                                                            const int32_t* __restrict__ rows_dev) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M || (rows_dev && row >= rows_dev[0])) return;
+    const int nv = E / 4;
+    const int b = sample ? sample[row] : row / T;
+    f32x4 x[NV], o[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = lane + 64 * u;
+        x[u] = c < nv ? reinterpret_cast<const f32x4*>(x1 + (int64_t)row * E)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        o[u] = c < nv ? reinterpret_cast<const f32x4*>(c1 + (int64_t)b * E)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int h = 0; h < H; ++h) {
+        const f32x4* g = reinterpret_cast<const f32x4*>(G + ((int64_t)b * H + h) * E);
+        const f32x4* d = reinterpret_cast<const f32x4*>(D + ((int64_t)b * H + h) * E);
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nv) {
+                const f32x4 gv = g[c];
+                part += x[u][0] * gv[0] + x[u][1] * gv[1] + x[u][2] * gv[2] + x[u][3] * gv[3];
+            }
+        }
+        const float z = (wave_sum(part) + sb[(int64_t)b * H + h]) * scale;
+        const float p = 1.0f / (1.0f + expf(-z));
+        if (lane == 0) p_out[(int64_t)row * H + h] = p;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nv) o[u] += d[c] * p;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nv) reinterpret_cast<f32x4*>(a2 + (int64_t)row * E)[c] = o[u];
+    }
+}
+
+// Backward: one workgroup per sample (its rows [r0, r1): seg_off, or T consecutive rows), a wavefront per row in turn.
+//   dp_h = d_a2 . D_h;  dz_h = dp_h p_h (1 - p_h) scale;  d_x1 += sum_h dz_h G_h;
+//   dG_h = sum_rows dz_h x1;  dD_h = sum_rows p_h d_a2;  dc1 = sum_rows d_a2;  dsb_h = sum_rows dz_h.
+// Heads in passes of four (register budget); the four wavefronts' partial sums meet in LDS one wavefront at a time.
+template <int NV>
+__global__ __launch_bounds__(256) void pair_gate_bwd_kernel(const float* __restrict__ d_a2, const float* __restrict__ x1,
+                                                            const float* __restrict__ p_in, const float* __restrict__ G,
+                                                            const float* __restrict__ D, const int32_t* __restrict__ seg_off,
+                                                            int T, int E, int H, float scale, float* __restrict__ d_x1,
+                                                            float* __restrict__ dG, float* __restrict__ dD,
+                                                            float* __restrict__ dc1, float* __restrict__ dsb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][E] + 4: dG x4, dD x4, dc1, dsb x4
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nv = E / 4;
+    const int r0 = seg_off ? seg_off[b] : b * T, r1 = seg_off ? seg_off[b + 1] : (b + 1) * T;
+    for (int h0 = 0; h0 < H; h0 += 4) {
+        f32x4 g[4][NV], d[4][NV], ag[4][NV], ad[4][NV], ac[NV];
+        float as[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int c = lane + 64 * u;
+                const bool ok = c < nv && h0 + hh < H;
+                g[hh][u] = ok ? reinterpret_cast<const f32x4*>(G + ((int64_t)b * H + h0 + hh) * E)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                d[hh][u] = ok ? reinterpret_cast<const f32x4*>(D + ((int64_t)b * H + h0 + hh) * E)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                ag[hh][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ad[hh][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) ac[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int row = r0 + wave; row < r1; row += 4) {
+            f32x4 x[NV], da[NV], dx[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int c = lane + 64 * u;
+                x[u] = c < nv ? reinterpret_cast<const f32x4*>(x1 + (int64_t)row * E)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                da[u] = c < nv ? reinterpret_cast<const f32x4*>(d_a2 + (int64_t)row * E)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                dx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (h0 == 0) ac[u] += da[u];
+            }
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) {
+                if (h0 + hh >= H) break;
+                float part = 0.f;
+#pragma unroll
+                for (int u = 0; u < NV; ++u)
+                    part += da[u][0] * d[hh][u][0] + da[u][1] * d[hh][u][1] + da[u][2] * d[hh][u][2] + da[u][3] * d[hh][u][3];
+                const float p = p_in[(int64_t)row * H + h0 + hh];
+                const float dz = wave_sum(part) * p * (1.0f - p) * scale;
+                as[hh] += dz;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    ag[hh][u] += x[u] * dz;
+                    ad[hh][u] += da[u] * p;
+                    dx[u] += g[hh][u] * dz;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int c = lane + 64 * u;
+                if (c < nv) reinterpret_cast<f32x4*>(d_x1 + (int64_t)row * E)[c] += dx[u];
+            }
+        }
+        // partial sums of the four wavefronts -> LDS, one wavefront at a time
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+                    for (int u = 0; u < NV; ++u) {
+                        const int c = lane + 64 * u;
+                        if (c < nv) {
+                            f32x4* pg = reinterpret_cast<f32x4*>(lds + (int64_t)hh * E) + c;
+                            f32x4* pd = reinterpret_cast<f32x4*>(lds + (int64_t)(4 + hh) * E) + c;
+                            *pg = w == 0 ? ag[hh][u] : *pg + ag[hh][u];
+                            *pd = w == 0 ? ad[hh][u] : *pd + ad[hh][u];
+                        }
+                    }
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int c = lane + 64 * u;
+                    if (c < nv) {
+                        f32x4* pc = reinterpret_cast<f32x4*>(lds + (int64_t)8 * E) + c;
+                        *pc = w == 0 ? ac[u] : *pc + ac[u];
+                    }
+                }
+                if (lane < 4) {
+                    float v = as[0];
+                    if (lane == 1) v = as[1];
+                    if (lane == 2) v = as[2];
+                    if (lane == 3) v = as[3];
+                    float* ps = lds + (int64_t)9 * E + lane;
+                    *ps = w == 0 ? v : *ps + v;
+                }
+            }
+            __syncthreads();
+        }
+        for (int idx = threadIdx.x; idx < 4 * nv; idx += 256) {
+            const int hh = idx / nv, c = idx - hh * nv;
+            if (h0 + hh < H) {
+                reinterpret_cast<f32x4*>(dG + ((int64_t)b * H + h0 + hh) * E)[c] = reinterpret_cast<const f32x4*>(lds + (int64_t)hh * E)[c];
+                reinterpret_cast<f32x4*>(dD + ((int64_t)b * H + h0 + hh) * E)[c] = reinterpret_cast<const f32x4*>(lds + (int64_t)(4 + hh) * E)[c];
+            }
+        }
+        if (h0 == 0)
+            for (int c = threadIdx.x; c < nv; c += 256)
+                reinterpret_cast<f32x4*>(dc1 + (int64_t)b * E)[c] = reinterpret_cast<const f32x4*>(lds + (int64_t)8 * E)[c];
+        if (threadIdx.x < 4 && h0 + (int)threadIdx.x < H) dsb[(int64_t)b * H + h0 + threadIdx.x] = lds[(int64_t)9 * E + threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// dK = k0 - k1, dV = v0 - v1 of each sample's projected memory rows ([B*2][E]) and sb[b,h] = b_q,h . dK_h
+__global__ __launch_bounds__(256) void pair_diff_fwd_kernel(const float* __restrict__ k2, const float* __restrict__ v2,
+                                                            const float* __restrict__ bq, int B, int E, int H,
+                                                            float* __restrict__ dk_out, float* __restrict__ dv_out,
+                                                            float* __restrict__ sb) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int nv = E / 4, hv = nv / H;
+    const f32x4* k0 = reinterpret_cast<const f32x4*>(k2 + (int64_t)(2 * b) * E);
+    const f32x4* v0 = reinterpret_cast<const f32x4*>(v2 + (int64_t)(2 * b) * E);
+    const f32x4* bq4 = reinterpret_cast<const f32x4*>(bq);
+    for (int c = lane; c < nv; c += 64) {
+        reinterpret_cast<f32x4*>(dk_out + (int64_t)b * E)[c] = k0[c] - k0[nv + c];
+        reinterpret_cast<f32x4*>(dv_out + (int64_t)b * E)[c] = v0[c] - v0[nv + c];
+    }
+    for (int h = 0; h < H; ++h) {
+        float part = 0.f;
+        for (int c = h * hv + lane; c < (h + 1) * hv; c += 64) {
+            const f32x4 d = k0[c] - k0[nv + c], q = bq4[c];
+            part += d[0] * q[0] + d[1] * q[1] + d[2] * q[2] + d[3] * q[3];
+        }
+        part = wave_sum(part);
+        if (lane == 0) sb[(int64_t)b * H + h] = part;
+    }
+}
+
+// Backward of pair_diff_fwd and of sb: given d(dK) (without the sb term), d(dV), d(sb), d(v1):
+//   d(dK)[b, h*dk + d] += dsb[b,h] b_q[h*dk + d];   dk2[2b] = d(dK)[b], dk2[2b+1] = -d(dK)[b];
+//   dv2[2b] = d(dV)[b], dv2[2b+1] = d(v1)[b] - d(dV)[b];   qb[b, h*dk + d] = dsb[b,h] dK[b, h*dk + d]  (its column sum is d b_q)
+__global__ __launch_bounds__(256) void pair_diff_bwd_kernel(const float* __restrict__ ddk, const float* __restrict__ ddv,
+                                                            const float* __restrict__ dsb, const float* __restrict__ dv1,
+                                                            const float* __restrict__ bq, const float* __restrict__ dkf,
+                                                            int B, int E, int H, float* __restrict__ dk2,
+                                                            float* __restrict__ dv2, float* __restrict__ qb) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int nv = E / 4, hv = nv / H;
+    for (int c = lane; c < nv; c += 64) {
+        const float s = dsb[(int64_t)b * H + c / hv];
+        const f32x4 a = reinterpret_cast<const f32x4*>(ddk + (int64_t)b * E)[c] + reinterpret_cast<const f32x4*>(bq)[c] * s;
+        reinterpret_cast<f32x4*>(dk2 + (int64_t)(2 * b) * E)[c] = a;
+        reinterpret_cast<f32x4*>(dk2 + (int64_t)(2 * b + 1) * E)[c] = -a;
+        const f32x4 v = reinterpret_cast<const f32x4*>(ddv + (int64_t)b * E)[c];
+        reinterpret_cast<f32x4*>(dv2 + (int64_t)(2 * b) * E)[c] = v;
+        reinterpret_cast<f32x4*>(dv2 + (int64_t)(2 * b + 1) * E)[c] = reinterpret_cast<const f32x4*>(dv1 + (int64_t)b * E)[c] - v;
+        reinterpret_cast<f32x4*>(qb + (int64_t)b * E)[c] = reinterpret_cast<const f32x4*>(dkf + (int64_t)b * E)[c] * s;
+    }
+}
+
 // ---- sums of consecutive row groups: out[g, :] = sum_{t<T} x[g*T + t, :]  (gradient of a row broadcast) ----
 __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ x, int G, int T, int E,
                                                         float* __restrict__ out, const int32_t* __restrict__ seg_off) {
@@ -1339,6 +1555,66 @@ int capdec_axpy_rows(const float* x, int x_div, float scale, int M, int E, float
     if (M == 0) return 0;
     hipLaunchKernelGGL(axpy_rows_kernel, dim3(grid_for((int64_t)M * E / 4)), dim3(256), 0, (hipStream_t)stream, x, x_div, scale,
                        M, E, y, accumulate);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_pair_diff(const float* k2, const float* v2, const float* bq, int B, int E, int H, float* dk, float* dv, float* sb,
+                     void* stream) {
+    CAPDEC_REQUIRE(k2 && v2 && bq && dk && dv && sb && B >= 0 && H >= 1 && E >= 4 && E % (4 * H) == 0);
+    if (!capdec_aligned16(k2) || !capdec_aligned16(v2) || !capdec_aligned16(bq) || !capdec_aligned16(dk) || !capdec_aligned16(dv))
+        return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(pair_diff_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, k2, v2, bq, B, E, H, dk, dv, sb);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_pair_diff_bwd(const float* ddk, const float* ddv, const float* dsb, const float* dv1, const float* bq,
+                         const float* dk, int B, int E, int H, float* dk2, float* dv2, float* qb, void* stream) {
+    CAPDEC_REQUIRE(ddk && ddv && dsb && dv1 && bq && dk && dk2 && dv2 && qb && B >= 0 && H >= 1 && E >= 4 && E % (4 * H) == 0);
+    if (!capdec_aligned16(ddk) || !capdec_aligned16(ddv) || !capdec_aligned16(dv1) || !capdec_aligned16(bq) ||
+        !capdec_aligned16(dk) || !capdec_aligned16(dk2) || !capdec_aligned16(dv2) || !capdec_aligned16(qb))
+        return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(pair_diff_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, ddk, ddv, dsb, dv1, bq, dk, B,
+                       E, H, dk2, dv2, qb);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_pair_gate_fwd(const float* x1, const float* G, const float* D, const float* c1, const float* sb,
+                         const int32_t* sample, int T, int M, int E, int H, float scale, float* a2, float* p,
+                         const int32_t* rows_dev, void* stream) {
+    CAPDEC_REQUIRE(x1 && G && D && c1 && sb && a2 && p && M >= 0 && T >= 1 && H >= 1 && E >= 4 && E % 4 == 0 && E <= 2048);
+    if (!capdec_aligned16(x1) || !capdec_aligned16(G) || !capdec_aligned16(D) || !capdec_aligned16(c1) || !capdec_aligned16(a2))
+        return CAPDEC_EALIGN;
+    if (M == 0) return 0;
+#define CAPDEC_CALL(NV_)                                                                                            \
+    hipLaunchKernelGGL(pair_gate_fwd_kernel<NV_>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x1, G, D, c1, sb, \
+                       sample, T, M, E, H, scale, a2, p, rows_dev)
+    CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
+#undef CAPDEC_CALL
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_pair_gate_bwd(const float* d_a2, const float* x1, const float* p, const float* G, const float* D,
+                         const int32_t* seg_off, int B, int T, int E, int H, float scale, float* d_x1, float* dG, float* dD,
+                         float* dc1, float* dsb, void* stream) {
+    CAPDEC_REQUIRE(d_a2 && x1 && p && G && D && d_x1 && dG && dD && dc1 && dsb && B >= 0 && T >= 1 && H >= 1 && E >= 4 &&
+                   E % 4 == 0 && E <= 1024);
+    if (!capdec_aligned16(d_a2) || !capdec_aligned16(x1) || !capdec_aligned16(G) || !capdec_aligned16(D) ||
+        !capdec_aligned16(d_x1) || !capdec_aligned16(dG) || !capdec_aligned16(dD) || !capdec_aligned16(dc1))
+        return CAPDEC_EALIGN;
+    if (B == 0) return 0;
+    const size_t smem = ((size_t)9 * E + 4) * sizeof(float);
+#define CAPDEC_CALL(NV_)                                                                                            \
+    hipLaunchKernelGGL(pair_gate_bwd_kernel<NV_>, dim3(B), dim3(256), smem, (hipStream_t)stream, d_a2, x1, p, G, D, seg_off, T, \
+                       E, H, scale, d_x1, dG, dD, dc1, dsb)
+    const int nvl = (E / 4 + 63) / 64;
+    if (nvl <= 1) { CAPDEC_CALL(1); } else if (nvl <= 2) { CAPDEC_CALL(2); } else { CAPDEC_CALL(4); }
+#undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

@@ -143,6 +143,33 @@ int capdec_softmax_rows(float* s, int64_t ld, int rows, int cols, int pad_to, co
 int capdec_softmax_rows_bwd(const float* p, float* dp, int64_t ld, int rows, int cols, int pad_to, float scale,
                             const int32_t* live, int live_idx, int mult, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Cross-attention over exactly two memory rows, training form (the ViT+CNN / YOLO+CNN heads: vitcnnattn_model.py:47-53,
+ * yolocnnattn_model.py:75-81 feeding transformer.py:86).  A softmax over two keys is a logistic function of the score
+ * difference: with dK = k0 - k1, dV = v0 - v1 (the projected memory rows of sample b) the block's output for a row x1 is
+ *     a2 = c1[b] + sum_h p_h D[b,h],   p_h = sigmoid((x1 . G[b,h] + sb[b,h]) * scale),
+ *     G[b,h] = W_q,h^T dK_h,  sb[b,h] = b_q,h . dK_h,  D[b,h] = W_o[:,h] dV_h,  c1[b] = W_o v1 + b_o,  scale = 1/sqrt(dk)
+ * so the W_q / W_o contractions over all rows and the attention launch become H dot products per row; everything with a
+ * [b] is B rows of work done with capdec_gemm.  G, D: [B][H][E]; c1: [B][E]; sb: [B][H]; p: [M][H].
+ *   capdec_pair_diff      k2, v2 [B*2][E] -> dK, dV [B][E], sb
+ *   capdec_pair_gate_fwd  one row per wavefront; sample (nullable): row -> sample, else row / T; rows_dev as elsewhere
+ *   capdec_pair_gate_bwd  one workgroup per sample (rows [seg_off[b], seg_off[b+1]) or [b*T, (b+1)*T)):
+ *                         d_x1 += sum_h dz_h G_h, dG, dD, dc1, dsb  (dz_h = (d_a2 . D_h) p_h (1 - p_h) scale)
+ *   capdec_pair_diff_bwd  d(dK) (+ the sb term), d(dV), d(v1) -> dk2, dv2 [B*2][E]; qb [B][E] whose column sum is d b_q
+ * E % (4*H) == 0 (diff), E % 4 == 0 and E <= 2048 (gate_fwd) / E <= 1024 (gate_bwd); pointers 16-byte aligned; CAPDEC_EINVAL /
+ * CAPDEC_EALIGN otherwise.  An empty batch (B == 0, M == 0) is a no-op.
+ * ------------------------------------------------------------------------------------------ */
+int capdec_pair_diff(const float* k2, const float* v2, const float* bq, int B, int E, int H, float* dk, float* dv, float* sb,
+                     void* stream);
+int capdec_pair_diff_bwd(const float* ddk, const float* ddv, const float* dsb, const float* dv1, const float* bq,
+                         const float* dk, int B, int E, int H, float* dk2, float* dv2, float* qb, void* stream);
+int capdec_pair_gate_fwd(const float* x1, const float* G, const float* D, const float* c1, const float* sb,
+                         const int32_t* sample, int T, int M, int E, int H, float scale, float* a2, float* p,
+                         const int32_t* rows_dev, void* stream);
+int capdec_pair_gate_bwd(const float* d_a2, const float* x1, const float* p, const float* G, const float* D,
+                         const int32_t* seg_off, int B, int T, int E, int H, float scale, float* d_x1, float* dG, float* dD,
+                         float* dc1, float* dsb, void* stream);
+
 /* Vocabulary projection fused with row arg-max (logits are never written):
  *   replaces fc2 + argmax, transformer.py:137,155 and cnnrnn_model.py:84-90 (log_softmax is
  *   monotone, so the arg-max of the logits is the arg-max of the log-probabilities).

@@ -112,6 +112,20 @@ int main() {
     EXPECT(capdec_softmax_rows(a, 4, 4, 5, 8, nullptr, 0, 1, nullptr), CAPDEC_EINVAL);            // ld < pad_to
     EXPECT(capdec_softmax_rows(a, 8, 0, 5, 8, nullptr, 0, 1, nullptr), 0);
     EXPECT(capdec_softmax_rows_bwd(a, nullptr, 8, 4, 5, 8, 1.f, nullptr, 0, 1, nullptr), CAPDEC_EINVAL);
+    // cross-attention over two memory rows, training form
+    EXPECT(capdec_pair_diff(nullptr, a, a, 1, 8, 2, a, a, a, nullptr), CAPDEC_EINVAL);
+    EXPECT(capdec_pair_diff(a, a, a, 1, 12, 2, a, a, a, nullptr), CAPDEC_EINVAL);                  // E % (4 H) != 0
+    EXPECT(capdec_pair_diff(una, a, a, 1, 8, 2, a, a, a, nullptr), CAPDEC_EALIGN);
+    EXPECT(capdec_pair_diff(a, a, a, 0, 8, 2, a, a, a, nullptr), 0);
+    EXPECT(capdec_pair_diff_bwd(a, a, a, a, a, a, 1, 8, 2, a, nullptr, a, nullptr), CAPDEC_EINVAL);
+    EXPECT(capdec_pair_diff_bwd(a, a, a, a, a, a, 1, 8, 2, a, una, a, nullptr), CAPDEC_EALIGN);
+    EXPECT(capdec_pair_gate_fwd(a, a, a, a, a, nullptr, 0, 4, 8, 2, 1.f, a, a, nullptr, nullptr), CAPDEC_EINVAL);   // T < 1
+    EXPECT(capdec_pair_gate_fwd(a, a, a, a, a, nullptr, 4, 4, 4096, 2, 1.f, a, a, nullptr, nullptr), CAPDEC_EINVAL);
+    EXPECT(capdec_pair_gate_fwd(a, una, a, a, a, nullptr, 4, 4, 8, 2, 1.f, a, a, nullptr, nullptr), CAPDEC_EALIGN);
+    EXPECT(capdec_pair_gate_fwd(a, a, a, a, a, nullptr, 4, 0, 8, 2, 1.f, a, a, nullptr, nullptr), 0);
+    EXPECT(capdec_pair_gate_bwd(a, a, a, a, a, nullptr, 1, 4, 2048, 2, 1.f, a, a, a, a, a, nullptr), CAPDEC_EINVAL);
+    EXPECT(capdec_pair_gate_bwd(a, a, a, a, a, nullptr, 1, 4, 8, 2, 1.f, una, a, a, a, a, nullptr), CAPDEC_EALIGN);
+    EXPECT(capdec_pair_gate_bwd(a, a, a, a, a, nullptr, 0, 4, 8, 2, 1.f, a, a, a, a, a, nullptr), 0);
     EXPECT(capdec_topk_rows(a, 4, 65, 3, a, ai, nullptr), CAPDEC_EINVAL);                          // n > 64
     EXPECT(capdec_topk_rows(a, 4, 9, 0, a, ai, nullptr), CAPDEC_EINVAL);
 

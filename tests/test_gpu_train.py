@@ -151,13 +151,15 @@ def test_softmax_nll_gradient_in_place_every_row_form(V):
     assert float(work[live:64].abs().max()) == 0.0 and bool((work[64:] == 7.0).all())
 
 
-def _run_stack(dec, enc, caps, ragged, shortcut=True, absorb=None):
+def _run_stack(dec, enc, caps, ragged, shortcut=True, absorb=None, pair=None):
     from capdec import autograd as AG
     from capdec import ops
     ids, tgt = caps[:, :-1].contiguous(), caps[:, 1:].contiguous()
     rg = ops.RaggedRows(ids, tgt, 0) if ragged else None
-    x, tape = AG.tf_forward(dec, enc, ids, 0.0, 0, single_row_shortcut=shortcut, ragged=rg, absorb_cross=absorb)
+    x, tape = AG.tf_forward(dec, enc, ids, 0.0, 0, single_row_shortcut=shortcut, ragged=rg, absorb_cross=absorb,
+                            pair_cross=pair)
     assert absorb is None or tape.absorbed == absorb
+    assert pair is None or tape.pair == pair
     if ragged:
         loss, saved = AG.vocab_loss(dec, x, rg.targets_c, rows=rg.rows)
     else:
@@ -218,6 +220,60 @@ def test_ragged_stack_equals_full_rows(B, T, S):
     floor = 1e-7 * max(float(gd.abs().max()) for gd in grads_d.values())
     for name, gd in grads_d.items():
         close(grads_r[name], gd.detach().cpu().numpy(), atol=floor, what=name)
+
+
+@pytest.mark.parametrize("ragged,pair,side", [(False, True, False), (True, True, False), (False, False, False),
+                                              (True, False, False), (True, True, True), (False, True, True)])
+def test_f4_two_memory_rows_against_golden(ragged, pair, side):
+    """Two memory rows (the ViT+CNN / YOLO+CNN heads): the logistic closed form of the cross-attention and the general
+    kernels, dense and on the live rows only, with and without the second stream: loss and every gradient against the
+    reference's."""
+    from capdec import autograd as AG
+    fx = load_golden("f4_decoder_forward")
+    dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
+    caps = t(fx["captions"]).cuda()
+    if side:
+        AG.use_side_stream(torch.cuda.Stream())
+    try:
+        loss, denc, grads, _ = _run_stack(dec, t(fx["enc_S2"]).cuda(), caps, ragged, pair=pair)
+        AG.join_side_stream()
+    finally:
+        AG.use_side_stream(None)
+    torch.cuda.synchronize()
+    close(loss[0], fx["loss_S2"], rtol=1e-5, what="loss")
+    close(denc, fx["denc_S2"], what="denc")
+    names = [n for n, _ in dec.named_parameters()]
+    atol = _noise_floor(fx, "grad__{}@S2", names)
+    for name in names:
+        close(grads[name], fx[f"grad__{name}@S2"], atol=atol, what=name)
+
+
+@pytest.mark.parametrize("B,T,ragged", [(37, 20, True), (37, 20, False), (130, 5, True), (3, 50, False)])
+def test_two_memory_rows_closed_form_equals_general_kernels(B, T, ragged):
+    """The closed form against the general cross-attention kernels on captions of every length and memories whose two
+    rows are far apart (probabilities near 0 and 1) or identical (exactly one half)."""
+    fx = load_golden("f4_decoder_forward")
+    dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
+    V, E = dec.fc2.weight.shape[0], dec.fc2.weight.shape[1]
+    g = torch.Generator().manual_seed(B * 10 + T)
+    caps = torch.zeros(B, T + 1, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(0, T, (1,), generator=g))
+        caps[b, 0] = 1
+        caps[b, 1:1 + n] = torch.randint(4, V, (n,), generator=g)
+        caps[b, 1 + n] = 2
+    caps = caps.cuda()
+    enc = torch.randn(B, 2, E, generator=g)
+    enc[0] *= 6.0
+    enc[1, 1] = enc[1, 0]
+    enc = enc.cuda()
+    loss_g, denc_g, grads_g, _ = _run_stack(dec, enc, caps, ragged, pair=False)
+    loss_p, denc_p, grads_p, _ = _run_stack(dec, enc, caps, ragged, pair=True)
+    close(loss_p[0], loss_g[0].cpu().numpy(), rtol=1e-6, what="loss")
+    close(denc_p, denc_g.cpu().numpy(), what="denc")
+    floor = 1e-6 * max(float(gd.abs().max()) for gd in grads_g.values())
+    for name, gd in grads_g.items():
+        close(grads_p[name], gd.detach().cpu().numpy(), atol=floor, what=name)
 
 
 @pytest.mark.parametrize("S,ragged", [(2, False), (5, False), (2, True), (5, True)])
