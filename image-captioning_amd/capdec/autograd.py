@@ -59,6 +59,35 @@ def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None, bia
     rows: int32 device scalar (a multiple of 32); only the first rows[0] rows of dy and x exist."""
     gw = _new(grads, prefix + ".weight", lin.weight)
     gb = _new(grads, prefix + ".bias", lin.bias) if (lin.bias is not None and not bias_done) else None
+    return _lin_bwd_into(gw, gb, lin.weight, dy, x, need_dx, mask, accum, rows)
+
+
+def _back_to_back(ts):
+    """One [n*rows, ...] view over n equally shaped tensors that lie back to back in one allocation (the trainer lays
+    the parameters and their gradients out that way), else None."""
+    t0 = ts[0]
+    step = t0.numel() * t0.element_size()
+    for i, t in enumerate(ts):
+        if (t.shape != t0.shape or not t.is_contiguous() or t.data_ptr() != t0.data_ptr() + i * step or
+                t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr()):
+            return None
+    return t0.detach().as_strided((len(ts) * t0.shape[0],) + tuple(t0.shape[1:]), t0.stride())
+
+
+def _stacked_projections(grads, prefix, lins):
+    """(W, gW, gb) of several Linear layers of one input as one stacked layer, when their weights, their biases and the
+    gradients of both lie back to back; else None."""
+    if any(ln.bias is None for ln in lins):
+        return None
+    names = [prefix + n for n in ("W_q", "W_k", "W_v")]
+    W = _back_to_back([ln.weight for ln in lins])
+    gW = _back_to_back([_new(grads, n + ".weight", ln.weight) for n, ln in zip(names, lins)])
+    gb = _back_to_back([_new(grads, n + ".bias", ln.bias) for n, ln in zip(names, lins)])
+    return None if (W is None or gW is None or gb is None) else (W, gW, gb)
+
+
+def _lin_bwd_into(gw, gb, W, dy, x, need_dx=True, mask=None, accum=None, rows=None):
+    """``_lin_bwd`` on explicit gradient buffers (gb None: no bias gradient wanted)."""
     if _side() is not None:
         main = torch.cuda.current_stream()
         _side().wait_stream(main)                        # dy and x are complete on the main stream
@@ -73,7 +102,7 @@ def _lin_bwd(grads, prefix, lin, dy, x, need_dx=True, mask=None, accum=None, bia
         if gb is not None:
             ops.colsum(dy, gb, rows_dev=rows)
     if need_dx:
-        return ops.linear_dgrad(dy, lin.weight, mask=mask, accum=accum, rows_dev=rows)
+        return ops.linear_dgrad(dy, W, mask=mask, accum=accum, rows_dev=rows)
     return None
 
 
@@ -479,14 +508,21 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
                                      dxsum=_new(grads, pre + "self_attn.W_o.bias", sa.W_o.bias), rows_dev=rows,
                                      seed_dev=t.seed_dev)
         d_ao = _lin_bwd(grads, pre + "self_attn.W_o", sa.W_o, d_a, c.ao, bias_done=True, rows=rows)
+        stk = _stacked_projections(grads, pre + "self_attn.", (sa.W_q, sa.W_k, sa.W_v))
         if rg is not None:
-            dq, dk, dv = ops.attention_bwd_ragged(c.qkv[0], c.qkv[1], c.qkv[2], d_ao, c.lse, rg, H)
+            dqkv = ops.attention_bwd_ragged(c.qkv[0], c.qkv[1], c.qkv[2], d_ao, c.lse, rg, H, packed=stk is not None)
         else:
-            dq, dk, dv = ops.attention_bwd(c.qkv[0], c.qkv[1], c.qkv[2], d_ao, c.lse, B, H, T, T, causal=True,
-                                           ids32=t.ids32)
-        _lin_bwd(grads, pre + "self_attn.W_q", sa.W_q, dq, c.x, accum=d_x, rows=rows)
-        _lin_bwd(grads, pre + "self_attn.W_k", sa.W_k, dk, c.x, accum=d_x, rows=rows)
-        _lin_bwd(grads, pre + "self_attn.W_v", sa.W_v, dv, c.x, accum=d_x, rows=rows)
+            dqkv = ops.attention_bwd(c.qkv[0], c.qkv[1], c.qkv[2], d_ao, c.lse, B, H, T, T, causal=True, ids32=t.ids32,
+                                     packed=stk is not None)
+        if stk is not None:
+            # the three projections as one layer of 3E outputs: one contraction each for the weight gradients, the bias
+            # gradients and the input gradient
+            _lin_bwd_into(stk[1], stk[2], stk[0], dqkv, c.x, accum=d_x, rows=rows)
+        else:
+            dq, dk, dv = dqkv
+            _lin_bwd(grads, pre + "self_attn.W_q", sa.W_q, dq, c.x, accum=d_x, rows=rows)
+            _lin_bwd(grads, pre + "self_attn.W_k", sa.W_k, dk, c.x, accum=d_x, rows=rows)
+            _lin_bwd(grads, pre + "self_attn.W_v", sa.W_v, dv, c.x, accum=d_x, rows=rows)
         dx = d_x
         if on_layer_done is not None:
             on_layer_done(l)          # every gradient of layer l is now enqueued

@@ -505,6 +505,13 @@ def linear_dgrad(dy, W, mask=None, accum=None, rows_dev=None):
     """dX = dY W  (dY [M,N], W [N,K]); zeroed where mask <= 0; added onto ``accum`` in place when given."""
     M, N = dy.shape
     K = W.shape[1]
+    if accum is None and mask is None and N >= 4096 and ((M + 63) // 64) * ((K + 63) // 64) <= 512:
+        # a long contraction into a small output (the vocabulary projection's input gradient at a small batch): too few
+        # output tiles to fill the chip, so the contraction is split over workgroups and summed with float atomics,
+        # like the weight gradients
+        out = torch.zeros((M, K), device=dy.device, dtype=torch.float32)
+        return gemm_raw(dy, W, out, M, K, N, _row_stride(dy, "dy"), _row_stride(W, "W"), _lib.GEMM_TQ | _lib.GEMM_ATOMIC,
+                        rows_dev=rows_dev)
     out = accum if accum is not None else torch.empty((M, K), device=dy.device, dtype=torch.float32)
     return gemm_raw(dy, W, out, M, K, N, _row_stride(dy, "dy"), _row_stride(W, "W"), _lib.GEMM_TQ, R=accum, mask=mask,
                     rows_dev=rows_dev)
@@ -623,13 +630,22 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None, 
     return d_add, d_x
 
 
-def attention_bwd(q, k, v, dout, lse, B, H, Tq, Tk, causal=False, ids32=None, dq=None, dk=None, dv=None, out=None):
+def attention_bwd(q, k, v, dout, lse, B, H, Tq, Tk, causal=False, ids32=None, dq=None, dk=None, dv=None, out=None,
+                  packed=False):
     """Backward of ``attention``; q/dout [B*Tq,E], k/v [B*Tk,E] 2-D views.  Returns (dq, dk, dv).
-    ``out`` (the forward output, optional) enables the one-pass kernel for long unmasked memories."""
+    ``out`` (the forward output, optional) enables the one-pass kernel for long unmasked memories.
+    packed (self-attention, Tq == Tk): the three gradients are the column blocks of one [M, 3E] tensor, which is returned
+    instead (one contraction against the stacked projection weights then gives the input gradient)."""
     lib = _lib.load()
     E = q.shape[1]
     dkh = E // H
     dev = q.device
+    pk = None
+    if packed:
+        if Tq != Tk or dq is not None or dk is not None or dv is not None:
+            raise RuntimeError("capdec attention_bwd: packed gradients need Tq == Tk and no caller buffers")
+        pk = torch.empty((B * Tq, 3 * E), device=dev, dtype=torch.float32)
+        dq, dk, dv = pk[:, :E], pk[:, E:2 * E], pk[:, 2 * E:]
     if dq is None:
         dq = torch.empty((B * Tq, E), device=dev, dtype=torch.float32)
     if dk is None:
@@ -648,7 +664,7 @@ def attention_bwd(q, k, v, dout, lse, B, H, Tq, Tk, causal=False, ids32=None, dq
                                         dq.data_ptr(), _row_stride(dq, "dq"), dk.data_ptr(), lddk, lddk * Tk,
                                         dv.data_ptr(), lddv, lddv * Tk, B, H, Tq, Tk, dkh, 1 if causal else 0, 0,
                                         _ptr(ids32), ldid, _stream()), "capdec_attention_bwd")
-    return dq, dk, dv
+    return pk if packed else (dq, dk, dv)
 
 
 def embed_bwd(ids, dx, demb, rows_dev=None):
@@ -730,19 +746,23 @@ def attention_ragged(q, k, v, rr, H, want_lse=False):
     return (out, lse) if want_lse else out
 
 
-def attention_bwd_ragged(q, k, v, dout, lse, rr, H):
+def attention_bwd_ragged(q, k, v, dout, lse, rr, H, packed=False):
     """Backward of ``attention_ragged``.  Returns (dq, dk, dv) [M,E]; the rows between the last sample and
-    ``rr.rows[0]`` are zero, those past it are not written."""
+    ``rr.rows[0]`` are zero, those past it are not written.  packed: one [M, 3E] tensor whose column blocks they are."""
     lib = _lib.load()
     M, E = q.shape
-    d = torch.empty((3, M, E), device=q.device, dtype=torch.float32)
+    if packed:
+        pk = torch.empty((M, 3 * E), device=q.device, dtype=torch.float32)
+        d, ld = (pk[:, :E], pk[:, E:2 * E], pk[:, 2 * E:]), 3 * E
+    else:
+        d, ld = torch.empty((3, M, E), device=q.device, dtype=torch.float32), E
     _lib.check(lib.capdec_attention_bwd_ragged(_chk(q).data_ptr(), _row_stride(q, "q"), _chk(k).data_ptr(),
                                                _row_stride(k, "k"), _chk(v).data_ptr(), _row_stride(v, "v"),
                                                _chk(dout).data_ptr(), _row_stride(dout, "dout"), _chk(lse).data_ptr(),
-                                               d[0].data_ptr(), E, d[1].data_ptr(), E, d[2].data_ptr(), E, rr.B, H, rr.T,
+                                               d[0].data_ptr(), ld, d[1].data_ptr(), ld, d[2].data_ptr(), ld, rr.B, H, rr.T,
                                                E // H, rr.ids_c.data_ptr(), rr.seq_off.data_ptr(), _stream()),
                "capdec_attention_bwd_ragged")
-    return d[0], d[1], d[2]
+    return pk if packed else (d[0], d[1], d[2])
 
 
 def cross_attention_ragged(q, k, v, rr, H, S, want_lse=False):

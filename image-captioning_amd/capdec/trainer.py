@@ -91,7 +91,12 @@ class CaptionTrainer:
         else:
             (self.fc_a, self.split), self.fc_b = _head_spec(model)
             for l in range(len(model.decoder_layers) - 1, -1, -1):
-                seg_names.append([n for n in named if n.startswith(f"decoder_layers.{l}.")])
+                names = [n for n in named if n.startswith(f"decoder_layers.{l}.")]
+                # the self-attention's three projection weights back to back, then their biases: the backward pass
+                # treats them as one stacked layer (autograd._stacked_projections)
+                first = [f"decoder_layers.{l}.self_attn.{w}.{k}" for k in ("weight", "bias") for w in ("W_q", "W_k", "W_v")]
+                first = [n for n in first if n in named]
+                seg_names.append(first + [n for n in names if n not in first])
             seg_names.append(["decoder_embedding.weight"])
         seg_names.append([n for n in named if n.split(".")[0] in ("fc1", "fc_vit", "fc_cnn", "fc_yolo", "batchnorm")])
         flat_names = [n for seg in seg_names for n in seg]

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
 // ---- LayerNorm backward -----------------------------------------------------------------------------
 // ds = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma, xhat = (s - mean) * rstd
 // d_add = ds ; d_x = ds * dropout mask ; dgamma += sum_r dy * xhat ; dbeta += sum_r dy
-constexpr int LNB_ROWS = 32;   // rows per workgroup (8 per wavefront); 16 and 64 both measured slower
+// Rows per workgroup (LNB_ROWS, a launch argument): 32 (8 per wavefront) for batches of thousands of rows (16 and 64 both
+// measured slower there); fewer, down to 8, when that would leave most of the chip without a workgroup.
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
@@ -151,7 +152,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                      float* __restrict__ d_add, float* __restrict__ d_x,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     float* __restrict__ dxsum, const int32_t* __restrict__ rows_dev) {
+                                                     float* __restrict__ dxsum, const int32_t* __restrict__ rows_dev,
+                                                     int LNB_ROWS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][3][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (rows_dev) M = min(M, rows_dev[0]);
@@ -538,11 +540,14 @@ __global__ void axpy_rows_kernel(const float* __restrict__ x, int x_div, float s
 // ids 0..3 for <PAD>/<SOS>/<EOS>/<UNK> (get_loader.py:28-29), <SOS> opens every caption and <PAD> fills the
 // tail of most.  Rows with an id below EB_HOT are therefore summed per workgroup in LDS first and leave as one
 // atomic per column; every other row goes straight to memory.  (Purely a speed heuristic: any ids are correct.)
-constexpr int EB_HOT = 4, EB_ROWS = 64;
+// A wavefront walks its rows one after the other (id, then the row, then the atomics: about 4 us a row), so a small
+// batch takes fewer rows per workgroup (EB_ROWS down to 8) to spread them over the chip; a large one is bound by the
+// atomics' throughput and keeps 64 rows per workgroup, whose hot rows leave as fewer atomics.
+constexpr int EB_HOT = 4;
 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
                                                         int rows, int E, int V, float* __restrict__ demb,
-                                                        const int32_t* __restrict__ rows_dev) {
+                                                        const int32_t* __restrict__ rows_dev, int EB_ROWS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [EB_HOT][E]
     __shared__ int used[EB_HOT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1516,9 +1521,11 @@ int capdec_layernorm_bwd_rows(const float* dy, const float* s, const float* mean
     static const bool wide_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<8>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 2048 * 4) == hipSuccess;
     if (!wide_ok) return CAPDEC_EINVAL;
+    int per = (M + 255) / 256;
+    per = M >= 8192 ? 32 : (per < 8 ? 8 : (per > 32 ? 32 : (per + 3) / 4 * 4));
 #define CAPDEC_CALL(NV_)                                                                                           \
-    hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 12 * E * sizeof(float),    \
-                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, seed_dev, d_add, d_x, dgamma, dbeta, dxsum, rows_dev)
+    hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3((M + per - 1) / per), dim3(256), 12 * E * sizeof(float),           \
+                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, seed_dev, d_add, d_x, dgamma, dbeta, dxsum, rows_dev, per)
     CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
@@ -1637,8 +1644,10 @@ int capdec_embed_bwd_rows(const int64_t* ids, const float* dx, int rows, int E, 
     CAPDEC_REQUIRE(ids && dx && demb && rows >= 0 && E >= 1 && V >= 1);
     if (rows == 0) return 0;
     CAPDEC_REQUIRE((size_t)EB_HOT * E * sizeof(float) <= 60 * 1024);
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + EB_ROWS - 1) / EB_ROWS), dim3(256), EB_HOT * E * sizeof(float),
-                       (hipStream_t)stream, ids, dx, rows, E, V, demb, rows_dev);
+    int per = (rows + 255) / 256;                      // about one workgroup per CU before the rows per workgroup grow
+    per = per < 8 ? 8 : (per > 64 ? 64 : (per + 3) / 4 * 4);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + per - 1) / per), dim3(256), EB_HOT * E * sizeof(float),
+                       (hipStream_t)stream, ids, dx, rows, E, V, demb, rows_dev, per);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }

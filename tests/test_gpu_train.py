@@ -655,6 +655,47 @@ def test_trainer_steps_match_oracle_training_loop(graph):
     assert int(got["batchnorm.num_batches_tracked"]) == 4
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_stacked_self_attention_projections_against_golden(ragged):
+    """With the three self-attention projection weights (and biases, and their gradients) laid out back to back, as the
+    trainer does, the backward pass runs them as one stacked layer: every gradient against the reference's."""
+    from capdec import autograd as AG
+    fx = load_golden("f4_decoder_forward")
+    dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"])).train()
+    E = dec.fc2.weight.shape[1]
+    grads = {}
+    with torch.no_grad():
+        for l, ly in enumerate(dec.decoder_layers):
+            lins = (ly.self_attn.W_q, ly.self_attn.W_k, ly.self_attn.W_v)
+            pw, pb = torch.empty(3 * E * E, device="cuda"), torch.empty(3 * E, device="cuda")
+            gw, gb = torch.zeros(3 * E * E, device="cuda"), torch.zeros(3 * E, device="cuda")
+            for i, (ln, nm) in enumerate(zip(lins, ("W_q", "W_k", "W_v"))):
+                w, b = pw[i * E * E:(i + 1) * E * E].view(E, E), pb[i * E:(i + 1) * E]
+                w.copy_(ln.weight)
+                b.copy_(ln.bias)
+                ln.weight.data, ln.bias.data = w, b
+                grads[f"decoder_layers.{l}.self_attn.{nm}.weight"] = gw[i * E * E:(i + 1) * E * E].view(E, E)
+                grads[f"decoder_layers.{l}.self_attn.{nm}.bias"] = gb[i * E:(i + 1) * E]
+            assert AG._stacked_projections(grads, f"decoder_layers.{l}.self_attn.", lins) is not None
+    caps = t(fx["captions"]).cuda()
+    ids, tgt = caps[:, :-1].contiguous(), caps[:, 1:].contiguous()
+    from capdec import ops
+    rg = ops.RaggedRows(ids, tgt, 0) if ragged else None
+    x, tape = AG.tf_forward(dec, t(fx["enc_S5"]).cuda(), ids, 0.0, 0, ragged=rg)
+    if ragged:
+        loss, saved = AG.vocab_loss(dec, x, rg.targets_c, rows=rg.rows)
+    else:
+        loss, saved = AG.vocab_loss(dec, x, tgt)
+    dx = AG.vocab_loss_bwd(dec, x, saved, grads)
+    denc = AG.tf_backward(dec, tape, dx, grads)
+    close(loss[0], fx["loss_S5"], rtol=1e-5, what="loss")
+    close(denc, fx["denc_S5"], what="denc")
+    names = [n for n, _ in dec.named_parameters()]
+    atol = _noise_floor(fx, "grad__{}@S5", names)
+    for name in names:
+        close(grads[name], fx[f"grad__{name}@S5"], atol=atol, what=name)
+
+
 def _rnn_from_fixture(fx):
     from models.cnnrnn_model import CNNtoRNN
     sd = sub_sd(fx, "sd__")
