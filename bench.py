@@ -141,9 +141,17 @@ def train_bench(device, rank, world, steps, warmup, fence, note=lambda m: None, 
     tflops = 3.0 * f_fwd * world * Bt * steps / dt / 1e12
     # FLOPs the step actually executes on this rank's batch: only the live rows R (positions with a counted target) go
     # through the stack and the vocabulary projection; with one memory row the cross-attention sub-layer is two
-    # B-row contractions per layer instead of four over all rows and two over the memory
+    # B-row contractions per layer instead of four over all rows and two over the memory, with two rows B-row
+    # contractions and a gate per live row
     R = live_rows
-    cross = 4 * Bt * E * E if S == 1 else (4 * R * E * E + 4 * Bt * S * E * E + 4 * R * S * E)
+    if S == 1:
+        cross = 4 * Bt * E * E
+    elif S == 2:
+        # logistic closed form: key/value projections of the two rows (8BE^2), G, D, c1 (2BE^2 each), then H dot
+        # products and H scaled additions of E per live row
+        cross = 14 * Bt * E * E + 4 * R * H * E
+    else:
+        cross = 4 * R * E * E + 4 * Bt * S * E * E + 4 * R * S * E
     f_exec = Lt * (12 * R * E * E + cross + 4 * live_sq * E) + 2 * R * E * V + 2 * Bt * Dh * E
     tflops_exec = 3.0 * f_exec * world * steps / dt / 1e12
     name = "cfg4 ViTCNN-Attn" if model_kind == "vitcnn" else "cfg3 ViT-Attn"

@@ -1315,6 +1315,7 @@ int capdec_tf_beam_search(const capdec_tf_model* m, const float* enc, int B, int
 struct TfBeamCacheWs {
     float *x, *y, *x2, *x1, *q, *ao, *hb;     // [N][E]
     float *cc, *ck, *cv, *encx;
+    float *pg, *pd, *psb;                     // S == 2: G, D [L][B][H][E] and sb [L][B][H] of the two-row closed form
     float* cache[2];                          // each [L][2][N][max_len][E]
     BeamBufs b;
 };
@@ -1327,10 +1328,16 @@ static size_t carve_tf_beam_cached(const capdec_tf_model* m, int B, int W, int S
     TfBeamCacheWs d;
     d.x = c.take<float>(NE); d.y = c.take<float>(NE); d.x2 = c.take<float>(NE); d.x1 = c.take<float>(NE);
     d.q = c.take<float>(NE); d.ao = c.take<float>(NE); d.hb = c.take<float>(NE);
-    d.cc = c.take<float>(S == 1 ? (size_t)m->L * B * m->E : 1);
-    d.ck = c.take<float>(S == 1 ? 1 : (size_t)m->L * NE * S);
-    d.cv = c.take<float>(S == 1 ? 1 : (size_t)m->L * NE * S);
-    d.encx = c.take<float>(S == 1 ? 1 : NE * S);
+    // one and two memory rows: per-sample constants shared by a sample's W hypotheses; longer memories: the projected
+    // memory once per hypothesis
+    const size_t BE = (size_t)B * m->E;
+    d.cc = c.take<float>(S <= 2 ? (size_t)m->L * BE : 1);
+    d.ck = c.take<float>(S == 1 ? 1 : (S == 2 ? (size_t)m->L * BE * 2 : (size_t)m->L * NE * S));
+    d.cv = c.take<float>(S == 1 ? 1 : (S == 2 ? (size_t)m->L * BE * 2 : (size_t)m->L * NE * S));
+    d.encx = c.take<float>(S <= 2 ? 1 : NE * S);
+    d.pg = c.take<float>(S == 2 ? (size_t)m->L * BE * m->H : 1);
+    d.pd = c.take<float>(S == 2 ? (size_t)m->L * BE * m->H : 1);
+    d.psb = c.take<float>(S == 2 ? (size_t)m->L * B * m->H : 1);
     for (int n = 0; n < 2; ++n) d.cache[n] = c.take<float>((size_t)m->L * 2 * NE * max_len);
     carve_beam_bufs(c, N, W, m->V, max_len, &d.b);
     if (w) *w = d;
@@ -1359,7 +1366,7 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
     const int E = m->E, V = m->V, H = m->H, L = m->L, dk = E / H, N = B * W;
     const size_t NE = (size_t)N * E, BE = (size_t)B * E;
     const int64_t ldtok = max_len + 1, cstride = (int64_t)max_len * E;
-    const bool s1 = S == 1;
+    const bool s1 = S == 1, s2 = S == 2;
     if (t_begin == 0) {
         hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos, w.b.unfinished, max_len);
         CAPDEC_LAUNCH_CHECK();
@@ -1370,6 +1377,11 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
                 CAPDEC_TRY(linear(enc, E, B, a.wv, a.bv, E, E, w.ao, E, nullptr, 0, 0, s));
                 CAPDEC_TRY(linear(w.ao, E, B, a.wo, a.bo, E, E, w.cc + l * BE, E, nullptr, 0, 0, s));
             }
+        } else if (s2) {
+            // two keys: a per-sample constant plus H logistic gates (see pair_memory_constants); w.q / w.ao are free
+            // until the first step
+            CAPDEC_TRY(project_memory(m, enc, B, 2, w.ck, w.cv, s));
+            CAPDEC_TRY(pair_memory_constants(m, w.ck, w.cv, B, w.q, w.ao, w.pg, w.pd, w.cc, w.psb, s));
         } else {
             hipLaunchKernelGGL(gather_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, enc, (const int32_t*)nullptr, W, N,
                                S * E, w.encx);
@@ -1398,6 +1410,12 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
             if (s1) {
                 CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, N, E, w.x2, nullptr,
                                                         s, ly.n2_g, ly.n2_b, w.cc + l * BE, W, nullptr));
+            } else if (s2) {
+                // norm1, the two-key cross-attention block and norm2 in one pass; hypothesis n belongs to sample n / W
+                CAPDEC_TRY(capdec_launch_layernorm_pair_rows(w.y, ly.n1_g, ly.n1_b, ly.n2_g, ly.n2_b, 1e-5f, N, E, w.x2,
+                                                             nullptr, nullptr, W, w.pg + (size_t)l * BE * H,
+                                                             w.pd + (size_t)l * BE * H, w.cc + l * BE,
+                                                             w.psb + (size_t)l * B * H, H, 1.0f / sqrtf((float)dk), s));
             } else {
                 CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n1_g, ly.n1_b, 1e-5f, N, E, w.x1, nullptr,
                                                         s));

@@ -116,7 +116,7 @@ def test_cached_beam_equals_full_prefix_beam_at_batch_256():
     torch.manual_seed(2)
     dec = plain_decoder(512, 10000, 4, 2).cuda().eval()
     g = torch.Generator().manual_seed(78)
-    for S in (1, 64):
+    for S in (1, 2, 64):
         enc = torch.randn(256, S, 512, generator=g).cuda()
         a = dec.beam_ids(enc, R.SOS, R.EOS, 3, 20, return_scores=True)
         b = dec.beam_ids(enc, R.SOS, R.EOS, 3, 20, return_scores=True, exact=True)
