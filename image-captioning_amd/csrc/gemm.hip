@@ -992,7 +992,16 @@ int launch_gemm_layout(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, 
         // tiles pay off only for very large outputs.
         const long tiles64 = (long)((maxI + 63) / 64) * ((maxJ + 63) / 64) * ngroups;
         const bool atomic = (a.flags & CAPDEC_GEMM_ATOMIC) != 0;
-        if (atomic) cfg = tiles64 >= 1024 ? 216 : 11;
+        // Contractions split over workgroups and summed with float atomics (weight gradients, the vocabulary input
+        // gradient of a small batch), measured over 704 ... 7488 contracted rows: the 32x64 two-k-group tile at BK 16
+        // beats the 64x64 one by 10-20 % on 512- and 1536-row outputs (12.8 vs 14.7 us at 704 rows, 44.9 vs 52.1 us
+        // at 7488) and by 30 % on the 10000-deep input gradient (92 vs 132 us at 704 rows; BK 16 divides 10000, so
+        // the tiles go straight into LDS).  The 10000 x 512 vocabulary weight gradient takes 128x128 tiles only from
+        // about 6000 contracted rows on (673 vs 703 us at 7488): they need a four-way split to fill the chip, and at
+        // 704 rows those four times 5 M atomics are the whole launch (149 vs 85 us).  The fixed-order split (partial
+        // slabs in a workspace sized by splitk_plan) keeps the rule its workspace was sized for.
+        if (atomic && a.x.splitk_ws) cfg = tiles64 >= 1024 ? 216 : 11;
+        else if (atomic) cfg = (tiles64 >= 1024 && a.K >= 8192) ? 216 : 316;
         else cfg = tiles64 <= 160 ? 32 : (tiles64 < 512 ? 316 : (tiles64 < 1024 ? 11 : 116));
     }
     if (cfg == 22) return launch_gemm_cfg<2, 2, 2, 32, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
