@@ -73,6 +73,10 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 // internal launchers shared between translation units (all return 0 / CAPDEC_E* / hipError_t)
 int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int flags, hipStream_t s,
                        const capdec_gemm_extra* extra = nullptr);
+// capdec_vocab_argmax_partial over the first rows_dev[0] rows only (nullable device scalar; whole 64- or 128-row
+// tiles: the partials of rows beyond it are left untouched)
+int capdec_launch_vocab_argmax_rows(const float* x, int64_t ldx, const float* W, const float* bias, int M, int V, int K,
+                                    float* part_val, int32_t* part_idx, const int32_t* rows_dev, hipStream_t s);
 int capdec_launch_layernorm_rows(const float* x, const float* add, int add_div, const int32_t* add_map,
                                  const float* gamma, const float* beta, float eps, int Mcap, int E, float* y,
                                  const int32_t* rows_dev, hipStream_t s, const float* gamma2 = nullptr,

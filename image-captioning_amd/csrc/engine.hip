@@ -730,6 +730,7 @@ struct DecodeWs {
     int32_t *tok, *done, *first_pad;
     int32_t *rowmap;         // [max_len][Mcap]
     int32_t *nrows;          // [max_len + 1]
+    int32_t *fin;            // [max_len] captions whose <EOS> came at step t
 };
 
 static int default_extra_cap(int B) { return ((B / 4 > 64 ? B / 4 : 64) + 63) / 64 * 64; }
@@ -771,13 +772,14 @@ static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, 
     d.first_pad = c.take<int32_t>((size_t)B);
     d.rowmap = c.take<int32_t>((size_t)max_len * (B + extra_cap));
     d.nrows = c.take<int32_t>((size_t)max_len + 1);
+    d.fin = c.take<int32_t>((size_t)max_len);
     if (w) *w = d;
     return c.off;
 }
 
 __global__ void cached_init_kernel(int32_t* tok, int64_t ldtok, int32_t* done, int32_t* first_pad, int64_t* out_ids,
-                                   int32_t* out_len, int32_t* dirty, int32_t* rowmap, int32_t* nrows, int B,
-                                   int max_len, int sos) {
+                                   int32_t* out_len, int32_t* dirty, int32_t* rowmap, int32_t* nrows,
+                                   int32_t* fin, int B, int max_len, int sos) {
     const int n = B * max_len;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     for (int idx = tid; idx < n; idx += nth) out_ids[idx] = -1;
@@ -790,10 +792,18 @@ __global__ void cached_init_kernel(int32_t* tok, int64_t ldtok, int32_t* done, i
         rowmap[b] = b * max_len;            // step 0: position 0 of every sample
     }
     for (int t = tid; t <= max_len; t += nth) nrows[t] = B;
+    for (int t = tid; t < max_len; t += nth) fin[t] = 0;
 }
 
 // One wavefront per sample: pick the token (as greedy_advance_kernel), then prepare step t+1: the sample's new row and,
 // if it holds a <PAD> and is still running, one re-run row per position from the first PAD on.
+// fin[s] counts the captions whose <EOS> came at step s.  The reference leaves its loop once every caption has one
+// (transformer.py:166-168); here the steps are enqueued ahead of time, so the loop ends on the device instead: a
+// launch that finds all B captions finished in the steps BEFORE its own (counts that no workgroup of this launch
+// changes, so every workgroup decides alike) records nothing - whatever a finished caption would predict is
+// discarded anyway - and sets the next step's row count to zero, which every kernel of that step (projections,
+// attention, LayerNorm, the vocabulary projection) reads before it does anything.  The step after the last <EOS>
+// still runs in full: one step is the price of not synchronising with the host.
 __global__ __launch_bounds__(256) void cached_advance_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
                                                              int B, int ntiles, int t, int max_len, int eos,
                                                              int32_t* tok, int64_t ldtok, int32_t* done,
@@ -801,9 +811,20 @@ __global__ __launch_bounds__(256) void cached_advance_kernel(const float* __rest
                                                              int32_t* dirty, const float* __restrict__ emb,
                                                              const float* __restrict__ pe, int E, int V,
                                                              float* __restrict__ x_next, int32_t* rowmap_next,
-                                                             int32_t* nrows_next, int extra_cap) {
+                                                             int32_t* nrows_next, int extra_cap, int32_t* fin) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    int fin_before = 0;
+    for (int s = lane; s < t; s += 64) fin_before += fin[s];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) fin_before += __shfl_xor(fin_before, o, 64);
+    if (fin_before >= B) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && nrows_next) {
+            nrows_next[0] = 0;
+            rowmap_next[0] = 0;          // waves beyond the row count still look up row 0's sample (see attention_kernel)
+        }
+        return;
+    }
     if (b >= B) return;
     float v = -INFINITY;
     int i = INT_MAX;
@@ -816,6 +837,7 @@ __global__ __launch_bounds__(256) void cached_advance_kernel(const float* __rest
         if (!done[b]) {
             if (i == eos) {
                 done[b] = 1;
+                atomicAdd(&fin[t], 1);
             } else {
                 const int n = out_len[b];
                 out_ids[(int64_t)b * max_len + n] = i;
@@ -927,7 +949,7 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
     CAPDEC_REQUIRE(!(flags & CAPDEC_DECODE_FOLD_MEMORY) || fold);      // forced but unavailable (S < 3 or E not built)
 
     hipLaunchKernelGGL(cached_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, w.first_pad, out_ids,
-                       out_len, out_dirty, w.rowmap, w.nrows, B, max_len, sos);
+                       out_len, out_dirty, w.rowmap, w.nrows, w.fin, B, max_len, sos);
     CAPDEC_LAUNCH_CHECK();
     CAPDEC_TRY(capdec_embed_pe(w.tok, 1, ldtok, m->emb, m->pe, 0, B, 1, E, V, w.x, stream));
 
@@ -1008,13 +1030,13 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
         // only the B new rows predict a token
         const bool probed = probe && t < probe->n;
         if (probed) CAPDEC_TRY((int)hipEventRecord((hipEvent_t)probe->begin[t], s));
-        CAPDEC_TRY(capdec_vocab_argmax_partial(w.x, E, m->fc2_w, m->fc2_b, B, V, E, w.pval, w.pidx, stream));
+        CAPDEC_TRY(capdec_launch_vocab_argmax_rows(w.x, E, m->fc2_w, m->fc2_b, B, V, E, w.pval, w.pidx, rows, s));
         if (probed) CAPDEC_TRY((int)hipEventRecord((hipEvent_t)probe->end[t], s));
         const bool last = (t + 1 == max_len);
         hipLaunchKernelGGL(cached_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
                            eos, w.tok, ldtok, w.done, w.first_pad, out_ids, out_len, out_dirty, m->emb, m->pe, E, V,
                            last ? nullptr : w.x, last ? nullptr : w.rowmap + (size_t)(t + 1) * Mcap,
-                           last ? nullptr : w.nrows + t + 1, extra_cap);
+                           last ? nullptr : w.nrows + t + 1, extra_cap, w.fin);
         CAPDEC_LAUNCH_CHECK();
     }
     return 0;

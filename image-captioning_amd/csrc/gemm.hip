@@ -751,12 +751,16 @@ template <int WI, int WJ, int BK, bool VEC, int MODE, bool DMA = false>
 __global__ __launch_bounds__(256, 5) void vocab_reduce_kernel(const float* __restrict__ W, const float* __restrict__ x,
                                                            int64_t ldx, const float* __restrict__ bias, int V, int M,
                                                            int K, float* __restrict__ out_a, void* __restrict__ out_b,
-                                                           int ntiles, TileMap map) {
+                                                           int ntiles, TileMap map,
+                                                           const int32_t* __restrict__ rows_dev) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BI = 64 * WI, BJ = 64 * WJ;
     int z, tile_i, tile_j;
     if (!tile_of_block(map, blockIdx.x, z, tile_i, tile_j)) return;
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
+    // rows_dev: only the first rows_dev[0] rows are wanted (a decode step after every caption has finished: none);
+    // the partials of the other rows are left as they are
+    if (rows_dev && j0 >= rows_dev[0]) return;
     f32x16 acc[WI][WJ];
     if (DMA) mainloop_dma<2, WI, WJ, BK, BK / 8>(W, x, (int64_t)K, ldx, V, M, i0, j0, 0, K / BK, lds, acc);
     else mainloop<2, WI, WJ, BK, VEC>(W, x, (int64_t)K, ldx, V, M, K, i0, j0, 0, (K + BK - 1) / BK, lds, acc);
@@ -1142,7 +1146,7 @@ int capdec_vocab_tiles(int V) { return (V + VOCAB_BI - 1) / VOCAB_BI; }
 size_t capdec_vocab_partial_elems(int M, int V) { return (M < 0 || V < 1) ? 0 : capdec_part_elems(M, capdec_vocab_tiles(V)); }
 
 static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const float* W, const float* bias, int M, int V,
-                               int K, float* out_a, void* out_b, hipStream_t s) {
+                               int K, float* out_a, void* out_b, hipStream_t s, const int32_t* rows_dev = nullptr) {
     CAPDEC_REQUIRE(x && W && bias && out_a && out_b && M >= 0 && V >= 1 && K >= 1 && ldx >= K);
     if (M == 0) return 0;
     const int nt = capdec_vocab_tiles(V);
@@ -1160,10 +1164,10 @@ static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const floa
     dim3 grid(make_tile_map(map, nt, wide ? (M + 127) / 128 : (M + 63) / 64, 1, false), 1, 1);
 #define CAPDEC_VR(WJ_, VEC_, MODE_)                                                                                    \
     hipLaunchKernelGGL((vocab_reduce_kernel<VOCAB_WI, WJ_, VBK, VEC_, MODE_>), grid, dim3(256), smem, s, W, x, ldx, bias, V, \
-                       M, K, out_a, out_b, nt, map)
+                       M, K, out_a, out_b, nt, map, rows_dev)
 #define CAPDEC_VD(WJ_, MODE_)                                                                                          \
     hipLaunchKernelGGL((vocab_reduce_kernel<VOCAB_WI, WJ_, VBK, true, MODE_, true>), grid, dim3(256), smem, s, W, x, ldx, bias, \
-                       V, M, K, out_a, out_b, nt, map)
+                       V, M, K, out_a, out_b, nt, map, rows_dev)
     if (dma) {
         if (mode == 0) { if (wide) CAPDEC_VD(2, 0); else CAPDEC_VD(1, 0); }
         else           { if (wide) CAPDEC_VD(2, 1); else CAPDEC_VD(1, 1); }
@@ -1184,6 +1188,15 @@ int capdec_vocab_argmax_partial(const float* x, int64_t ldx, const float* W, con
                                 float* part_val, int32_t* part_idx, void* stream) {
     return vocab_reduce_launch(0, x, ldx, W, bias, M, V, K, part_val, part_idx, (hipStream_t)stream);
 }
+
+}  // extern "C"
+
+int capdec_launch_vocab_argmax_rows(const float* x, int64_t ldx, const float* W, const float* bias, int M, int V, int K,
+                                    float* part_val, int32_t* part_idx, const int32_t* rows_dev, hipStream_t s) {
+    return vocab_reduce_launch(0, x, ldx, W, bias, M, V, K, part_val, part_idx, s, rows_dev);
+}
+
+extern "C" {
 
 int capdec_argmax_finalize(const float* part_val, const int32_t* part_idx, int M, int ntiles, int32_t* out_idx,
                            float* out_val, void* stream) {

@@ -435,6 +435,56 @@ def test_f5_greedy_rows_finish_early():
     check_greedy(got, sd, t(fx["c_enc"]), int(fx["H"]), 30, want_rows=unpad(fx["c_ids"]))
 
 
+def test_greedy_loop_ends_on_the_device_once_every_caption_has_finished():
+    """The reference leaves the loop when every caption holds an <EOS> (transformer.py:166-168).  The cached decoder
+    enqueues all max_length steps ahead of time; once the device-side count of running captions is zero the remaining
+    steps run on no rows.  Same tokens as with the loop run to the end (an <EOS> id that never occurs keeps every row
+    alive, its tokens up to each caption's <EOS> position must agree), same tokens as the oracle, and a fraction of the
+    time."""
+    import time
+    from capdec.engine import tf_greedy_ids
+    torch.manual_seed(21)
+    V, E, H, L, B, ML = 10000, 512, 4, 2, 512, 50
+    dec = plain_decoder(E, V, H, L).cuda().eval()
+    with torch.no_grad():
+        # logits of a default-init decoder: standard deviation 0.58, the largest of 10000 about 2.3
+        dec.fc2.bias[R.EOS] += 1.9
+    g = torch.Generator().manual_seed(9)
+    enc = torch.randn(B, 1, E, generator=g)
+    # some rows of a random decoder repeat one token for ever; a row's caption does not depend on the rest of the batch,
+    # so the batch is cut down to the rows that finish within 30 steps: finishing times spread over 0 .. 29
+    _, lens0, _ = tf_greedy_ids(dec, enc.cuda(), ML, R.SOS, R.EOS)
+    keep = lens0 < 30
+    enc = enc[keep].contiguous()
+    B = enc.shape[0]
+    assert B >= 64 and int(lens0[keep].max()) >= 3, (B, lens0[keep].max())
+    enc_d = enc.cuda()
+
+    def timed(eos):
+        tf_greedy_ids(dec, enc_d, ML, R.SOS, eos)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = tf_greedy_ids(dec, enc_d, ML, R.SOS, eos)
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+
+    (ids, lens, _), dt = timed(R.EOS)
+    (ids_full, lens_full, _), dt_full = timed(V + 7)       # no such token: every row runs all 50 steps
+    lens_l = lens.tolist()
+    assert lens_l == lens0[keep].tolist() and max(lens_l) < 30
+    assert min(lens_full.tolist()) == ML
+    for b in range(B):
+        n = lens_l[b]
+        assert ids[b, :n].tolist() == ids_full[b, :n].tolist()
+        assert int(ids_full[b, n]) == R.EOS
+    got = [row[:n] for row, n in zip(ids.tolist(), lens_l)]
+    check_greedy(got[:48], cpu_sd(dec), enc[:48], H, ML)
+    print(f"early exit: {B} captions, the longest {max(lens_l)} of {ML} steps, {dt * 1e3:.2f} ms against {dt_full * 1e3:.2f} ms")
+    assert dt < 0.85 * dt_full
+    (ids2, lens2, _), _ = timed(R.EOS)                     # and the same again from run to run
+    assert torch.equal(ids2, ids) and torch.equal(lens2, lens)
+
+
 def test_greedy_api_strings_and_limits():
     fx = load_golden("f5_greedy")
     sd = sub_sd(fx, "c__sd__")
