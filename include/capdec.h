@@ -445,8 +445,11 @@ size_t capdec_tf_decode_workspace_bytes(const capdec_tf_model* m, int B, int S, 
  * inside the step (through the same kernels, k/v rewritten in the cache) as extra rows after the B new ones; at
  * most extra_cap of them per step (0 = default max(64, B/4)).  out_dirty [B] is set to 1 for a sample whose
  * re-run rows did not fit: only such samples need capdec_tf_greedy_decode_exact afterwards.
- * All max_len steps are always enqueued (there is no host sync to test the reference's all-rows-done early exit,
- * which has no visible effect on the outputs).  With S == 1 the softmax over the single memory row is exactly 1,
+ * All max_len steps are always enqueued without a host sync; the reference's all-rows-done early exit
+ * (transformer.py:166-168) happens on the device: the kernel that picks the tokens counts the captions that
+ * finish at each step, and once all B have finished the later steps run on a device-side row count of zero (every
+ * kernel of a step returns at once; about a sixth of a full step's time).  The outputs are the same either way.
+ * With S == 1 the softmax over the single memory row is exactly 1,
  * so the cross-attention block reduces to one vector per sample and layer that is computed once. */
 /* Optional timing probe: HIP events recorded on `stream` right before / after the vocabulary-projection
  * kernel of decode step t, for t < n.  Events are created with capdec_event_create; read them with
