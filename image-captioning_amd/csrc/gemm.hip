@@ -846,6 +846,104 @@ __global__ __launch_bounds__(256, 5) void vocab_reduce_kernel(const float* __res
     }
 }
 
+// ---- vocabulary arg-max for batches of at most 32 rows (the reference's own decode runs at batch 32) --------------
+// The tiling above gives such a batch V/64 workgroups whose wavefronts each walk the whole contraction for a 64-row
+// tile that is half empty: 18.6 us at 32 x 5000 x 512, a tenth of it arithmetic.  Here a workgroup of eight wavefronts
+// owns one 64-id vocabulary tile (the same tile numbering, so the partial-result layout is unchanged): two wavefronts
+// side by side on the vocabulary axis, four deep on the contraction; each reads its own k range of W and x straight
+// from memory into MFMA fragments (16 bytes per lane: the two lane halves supply k and k + 4 of a group of eight;
+// nothing is shared, so no LDS staging), the four partial tiles of a vocabulary half meet in LDS and are added in a
+// fixed order.  Vocabulary ids on the accumulator registers, rows on the lanes, as above.
+__global__ __launch_bounds__(512) void vocab_argmax_small_kernel(const float* __restrict__ W, const float* __restrict__ x,
+                                                                 int64_t ldx, const float* __restrict__ bias, int V,
+                                                                 int M, int K, float* __restrict__ out_val,
+                                                                 int* __restrict__ out_idx, int ntiles,
+                                                                 const int32_t* __restrict__ rows_dev) {
+    __shared__ float red[8][16][64];
+    __shared__ float sm_v[2][32];
+    __shared__ int sm_i[2][32];
+    if (rows_dev && rows_dev[0] <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wv = wave & 1, wk = wave >> 1;
+    const int tile = blockIdx.x, i0 = tile * 64 + 32 * wv;
+    const int nk = K / 8;                                    // k-chunks of 8
+    const int per = (nk + 3) / 4;
+    const int kc0 = wk * per, kc1 = min(nk, kc0 + per);
+    const float* wa = W + (int64_t)min(i0 + r, V - 1) * K + 4 * h;       // ids past the vocabulary repeat the last one
+    const float* xa = x + (int64_t)min(r, M - 1) * ldx + 4 * h;          // rows past the batch likewise: never stored
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    // k-chunks per batch of loads: four chunks are one 128-byte line of each row.  Batches of eight (a wavefront's
+    // whole range in flight at K = 512) are slower, 15.4 against 13.3 us: a load instruction touches 32 rows, and the
+    // lines the eight wavefronts then hold open exceed the 32 KiB vector cache.
+    constexpr int U = 4;
+    f32x4 av[2][U], bv[2][U];
+    auto fetch = [&](int set, int kc) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int k = kc + i;
+            av[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < kc1) {
+                av[set][i] = *reinterpret_cast<const f32x4*>(wa + 8 * k);
+                bv[set][i] = *reinterpret_cast<const f32x4*>(xa + 8 * k);
+            }
+        }
+    };
+    auto multiply = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < U; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][i][m], bv[set][i][m], acc, 0, 0, 0);
+    };
+    // the loads of the next batch are in flight while the current one is multiplied
+    fetch(0, kc0);
+    for (int kc = kc0; kc < kc1; kc += 2 * U) {
+        fetch(1, kc + U);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0, kc + 2 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave][e][lane] = acc[e];
+    __syncthreads();
+    if (wk == 0) {
+        // this wavefront's vocabulary half: the four k-partials in a fixed order, bias, lane-local winner (registers walk
+        // the ids in increasing order for a fixed lane half, so a strict compare keeps the lowest id on ties)
+        float best = -INFINITY;
+        int bidx = INT_MAX;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + acc_row(e, h);
+            const float v = ((red[wv][e][lane] + red[2 + wv][e][lane]) + (red[4 + wv][e][lane] + red[6 + wv][e][lane])) +
+                            (i < V ? bias[i] : 0.f);
+            if (i < V && v > best) { best = v; bidx = i; }
+        }
+        const float v2 = __shfl_xor(best, 32, 64);
+        const int i2 = __shfl_xor(bidx, 32, 64);
+        argmax_merge(best, bidx, v2, i2);
+        if (h == 0) {
+            sm_v[wv][r] = best;
+            sm_i[wv][r] = bidx;
+        }
+    }
+    __syncthreads();
+    if (tid < 32 && tid < M) {
+        float a0 = sm_v[0][tid];
+        int b0 = sm_i[0][tid];
+        argmax_merge(a0, b0, sm_v[1][tid], sm_i[1][tid]);
+        const int64_t o = capdec_part_off(tid, tile, ntiles);
+        out_val[o] = a0;
+        out_idx[o] = b0;
+    }
+}
+
 // one wavefront per row: merge the per-tile winners
 __global__ __launch_bounds__(256) void argmax_finalize_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
                                                               int M, int ntiles, int* __restrict__ out_idx,
@@ -1151,6 +1249,14 @@ static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const floa
     if (M == 0) return 0;
     const int nt = capdec_vocab_tiles(V);
     const bool vec = (K % 4 == 0) && (ldx % 4 == 0) && capdec_aligned16(x) && capdec_aligned16(W);
+    if (mode == 0 && M <= 32 && vec && K % 8 == 0 && g_staging != 1) {
+        // a batch of at most 32 rows: one workgroup of eight wavefronts per vocabulary tile (18.6 -> 13.3 us at
+        // 32 x 5000 x 512)
+        hipLaunchKernelGGL(vocab_argmax_small_kernel, dim3(nt), dim3(512), 0, s, W, x, ldx, bias, V, M, K, out_a,
+                           static_cast<int*>(out_b), nt, rows_dev);
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
     // samples sit on the j (lane) axis: 128-wide tiles when there are enough rows to fill the chip
     const bool wide = ((long)nt * ((M + 127) / 128) >= 192);
     constexpr int VBK = 16;   // 64x128 tile at BK 16: 30 KiB of LDS, five workgroups per CU (1256 tiles at V=10000, M=1024: 4.9 per CU)

@@ -142,7 +142,9 @@ def test_attention_shapes(ops, B, H, Tq, Tk, dk):
 
 def test_vocab_argmax_and_nll(ops):
     g = torch.Generator().manual_seed(11)
-    for M, V, K in ((5, 50, 64), (300, 10000, 512), (64, 5000, 512), (1024, 777, 128)):
+    # (up to 32 rows with K a multiple of 8: the eight-wavefront small-batch kernel; K = 132: the general one)
+    for M, V, K in ((5, 50, 64), (300, 10000, 512), (64, 5000, 512), (1024, 777, 128), (32, 5000, 512), (17, 777, 136),
+                    (1, 10000, 512), (32, 333, 8), (9, 130, 132)):
         x = torch.randn(M, K, generator=g)
         W = torch.randn(V, K, generator=g) / K ** 0.5
         b = torch.randn(V, generator=g) * 0.1
@@ -167,6 +169,32 @@ def test_argmax_ties_resolve_to_lowest_index(ops):
     W[[17, 150, 299]] = 1.0      # three exactly equal winners in different tiles / lane halves
     idx, _ = ops.vocab_argmax(x, W.cuda(), torch.zeros(300).cuda())
     assert torch.all(idx.cpu() == 17)
+    idx, _ = ops.vocab_argmax(x[:29], W.cuda(), torch.zeros(300).cuda())       # the small-batch kernel
+    assert torch.all(idx.cpu() == 17)
+
+
+def test_small_batch_vocab_argmax_against_the_general_kernel(ops):
+    """Batches of at most 32 rows take a kernel of their own (a workgroup of eight wavefronts per vocabulary tile, the
+    contraction split four ways); the tuning build's staging override sends the same call through the general kernel.
+    Same winners (near-ties aside), values within rounding of each other."""
+    from capdec import _lib
+    g = torch.Generator().manual_seed(23)
+    for M, V, K in ((32, 5000, 512), (32, 10000, 512), (7, 1000, 256)):
+        x = torch.randn(M, K, generator=g).cuda()
+        W = (torch.randn(V, K, generator=g) / K ** 0.5).cuda()
+        b = (torch.randn(V, generator=g) * 0.1).cuda()
+        with _lib.tuning_build() as lib:
+            idx_s, val_s = ops.vocab_argmax(x, W, b)
+            lib.capdec_gemm_force_staging(1)
+            try:
+                idx_g, val_g = ops.vocab_argmax(x, W, b)
+            finally:
+                lib.capdec_gemm_force_staging(0)
+        close(val_s, val_g.cpu().double(), rtol=1e-5)
+        logits = x.cpu().double() @ W.cpu().double().t() + b.cpu().double()
+        top2 = logits.topk(2, -1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-5 * logits.abs().max()
+        assert torch.equal(idx_s.cpu()[safe], idx_g.cpu()[safe])
 
 
 def test_batchnorm_fold_and_train(ops):
