@@ -850,16 +850,23 @@ __global__ __launch_bounds__(256, 5) void vocab_reduce_kernel(const float* __res
 // The tiling above gives such a batch V/64 workgroups whose wavefronts each walk the whole contraction for a 64-row
 // tile that is half empty: 18.6 us at 32 x 5000 x 512, a tenth of it arithmetic.  Here a workgroup of eight wavefronts
 // owns one 64-id vocabulary tile (the same tile numbering, so the partial-result layout is unchanged): two wavefronts
-// side by side on the vocabulary axis, four deep on the contraction; each reads its own k range of W and x straight
-// from memory into MFMA fragments (16 bytes per lane: the two lane halves supply k and k + 4 of a group of eight;
-// nothing is shared, so no LDS staging), the four partial tiles of a vocabulary half meet in LDS and are added in a
-// fixed order.  Vocabulary ids on the accumulator registers, rows on the lanes, as above.
+// side by side on the vocabulary axis, four deep on the contraction.  Nothing is shared between wavefronts, so there is
+// no workgroup barrier in the loop: a wavefront fetches its own 32 x 32 blocks of W and x with whole-line loads (eight
+// lanes per 128-byte row segment), turns them into MFMA fragments through a private LDS region (rows padded to 36
+// floats: the 16-byte fragment reads of 16 lanes fall on distinct banks), and the four partial tiles of a vocabulary
+// half meet in LDS at the end, added in a fixed order.  (Fragments read straight from memory - 16 bytes per lane, 32
+// rows per load instruction - ran at 13.3 us: the lines eight wavefronts hold open overflow the 32 KiB vector cache.)
+// Vocabulary ids on the accumulator registers, rows on the lanes, as above.  K must be a multiple of 32.
+constexpr int VS_LD = 36;                                   // floats per staged row
+constexpr int VS_WAVE_FLOATS = 2 * 32 * VS_LD;              // W block + x block of one wavefront
+constexpr size_t VS_LDS_BYTES = (size_t)8 * VS_WAVE_FLOATS * sizeof(float);
+
 __global__ __launch_bounds__(512) void vocab_argmax_small_kernel(const float* __restrict__ W, const float* __restrict__ x,
                                                                  int64_t ldx, const float* __restrict__ bias, int V,
                                                                  int M, int K, float* __restrict__ out_val,
                                                                  int* __restrict__ out_idx, int ntiles,
                                                                  const int32_t* __restrict__ rows_dev) {
-    __shared__ float red[8][16][64];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float sm_v[2][32];
     __shared__ int sm_i[2][32];
     if (rows_dev && rows_dev[0] <= 0) return;
@@ -867,62 +874,78 @@ __global__ __launch_bounds__(512) void vocab_argmax_small_kernel(const float* __
     const int r = lane & 31, h = lane >> 5;
     const int wv = wave & 1, wk = wave >> 1;
     const int tile = blockIdx.x, i0 = tile * 64 + 32 * wv;
-    const int nk = K / 8;                                    // k-chunks of 8
-    const int per = (nk + 3) / 4;
-    const int kc0 = wk * per, kc1 = min(nk, kc0 + per);
-    const float* wa = W + (int64_t)min(i0 + r, V - 1) * K + 4 * h;       // ids past the vocabulary repeat the last one
-    const float* xa = x + (int64_t)min(r, M - 1) * ldx + 4 * h;          // rows past the batch likewise: never stored
+    const int nb = K / 32;                                   // 32-float blocks of the contraction
+    const int per = (nb + 3) / 4;
+    const int b0 = wk * per, b1 = min(nb, b0 + per);
+    float* sw = lds + wave * VS_WAVE_FLOATS;                 // [32][VS_LD] block of W
+    float* sx = sw + 32 * VS_LD;                             // [32][VS_LD] block of x
+    // loads: instruction i covers rows 8i .. 8i+7, eight lanes per row
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const float* wg[4];
+    const float* xg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wg[i] = W + (int64_t)min(i0 + 8 * i + lrow, V - 1) * K + 4 * lslot;    // ids past the vocabulary repeat the last one
+        xg[i] = x + (int64_t)min(8 * i + lrow, M - 1) * ldx + 4 * lslot;       // rows past the batch likewise: never stored
+    }
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    // k-chunks per batch of loads: four chunks are one 128-byte line of each row.  Batches of eight (a wavefront's
-    // whole range in flight at K = 512) are slower, 15.4 against 13.3 us: a load instruction touches 32 rows, and the
-    // lines the eight wavefronts then hold open exceed the 32 KiB vector cache.
-    constexpr int U = 4;
-    f32x4 av[2][U], bv[2][U];
-    auto fetch = [&](int set, int kc) {
+    f32x4 wr[2][4], xr[2][4];
+    auto fetch = [&](int set, int b) {
+        if (b < b1) {
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const int k = kc + i;
-            av[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bv[set][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (k < kc1) {
-                av[set][i] = *reinterpret_cast<const f32x4*>(wa + 8 * k);
-                bv[set][i] = *reinterpret_cast<const f32x4*>(xa + 8 * k);
+            for (int i = 0; i < 4; ++i) {
+                wr[set][i] = *reinterpret_cast<const f32x4*>(wg[i] + 32 * b);
+                xr[set][i] = *reinterpret_cast<const f32x4*>(xg[i] + 32 * b);
             }
         }
     };
-    auto multiply = [&](int set) {
+    auto consume = [&](int set, int b) {
+        if (b >= b1) return;
 #pragma unroll
-        for (int i = 0; i < U; ++i)
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(sw + (8 * i + lrow) * VS_LD + 4 * lslot) = wr[set][i];
+            *reinterpret_cast<f32x4*>(sx + (8 * i + lrow) * VS_LD + 4 * lslot) = xr[set][i];
+        }
+        // LDS serves one wavefront's accesses in order: the block written above is what the reads below see
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][i][m], bv[set][i][m], acc, 0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sw + r * VS_LD + 8 * c + 4 * h);
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(sx + r * VS_LD + 8 * c + 4 * h);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[m], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
     };
-    // the loads of the next batch are in flight while the current one is multiplied
-    fetch(0, kc0);
-    for (int kc = kc0; kc < kc1; kc += 2 * U) {
-        fetch(1, kc + U);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(0);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(0, kc + 2 * U);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(1);
-        __builtin_amdgcn_sched_barrier(0);
+    // the loads of the next block are in flight while the current one is multiplied
+    fetch(0, b0);
+    for (int b = b0; b < b1; b += 2) {
+        fetch(1, b + 1);
+        consume(0, b);
+        fetch(0, b + 2);
+        consume(1, b + 1);
     }
+    // partial tiles: each wavefront's own staging region holds its 16 x 64 values
+    float* red = lds + wave * VS_WAVE_FLOATS;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) red[wave][e][lane] = acc[e];
+    for (int e = 0; e < 16; ++e) red[e * 64 + lane] = acc[e];
     __syncthreads();
     if (wk == 0) {
         // this wavefront's vocabulary half: the four k-partials in a fixed order, bias, lane-local winner (registers walk
         // the ids in increasing order for a fixed lane half, so a strict compare keeps the lowest id on ties)
+        const float* p0 = lds + (size_t)(0 + wv) * VS_WAVE_FLOATS;
+        const float* p1 = lds + (size_t)(2 + wv) * VS_WAVE_FLOATS;
+        const float* p2 = lds + (size_t)(4 + wv) * VS_WAVE_FLOATS;
+        const float* p3 = lds + (size_t)(6 + wv) * VS_WAVE_FLOATS;
         float best = -INFINITY;
         int bidx = INT_MAX;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int i = i0 + acc_row(e, h);
-            const float v = ((red[wv][e][lane] + red[2 + wv][e][lane]) + (red[4 + wv][e][lane] + red[6 + wv][e][lane])) +
-                            (i < V ? bias[i] : 0.f);
+            const int o = e * 64 + lane;
+            const float v = ((p0[o] + p1[o]) + (p2[o] + p3[o])) + (i < V ? bias[i] : 0.f);
             if (i < V && v > best) { best = v; bidx = i; }
         }
         const float v2 = __shfl_xor(best, 32, 64);
@@ -936,11 +959,11 @@ __global__ __launch_bounds__(512) void vocab_argmax_small_kernel(const float* __
     __syncthreads();
     if (tid < 32 && tid < M) {
         float a0 = sm_v[0][tid];
-        int b0 = sm_i[0][tid];
-        argmax_merge(a0, b0, sm_v[1][tid], sm_i[1][tid]);
+        int bb = sm_i[0][tid];
+        argmax_merge(a0, bb, sm_v[1][tid], sm_i[1][tid]);
         const int64_t o = capdec_part_off(tid, tile, ntiles);
         out_val[o] = a0;
-        out_idx[o] = b0;
+        out_idx[o] = bb;
     }
 }
 
@@ -1249,10 +1272,11 @@ static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const floa
     if (M == 0) return 0;
     const int nt = capdec_vocab_tiles(V);
     const bool vec = (K % 4 == 0) && (ldx % 4 == 0) && capdec_aligned16(x) && capdec_aligned16(W);
-    if (mode == 0 && M <= 32 && vec && K % 8 == 0 && g_staging != 1) {
-        // a batch of at most 32 rows: one workgroup of eight wavefronts per vocabulary tile (18.6 -> 13.3 us at
-        // 32 x 5000 x 512)
-        hipLaunchKernelGGL(vocab_argmax_small_kernel, dim3(nt), dim3(512), 0, s, W, x, ldx, bias, V, M, K, out_a,
+    if (mode == 0 && M <= 32 && vec && K % 32 == 0 && g_staging != 1) {
+        // a batch of at most 32 rows: one workgroup of eight wavefronts per vocabulary tile
+        static const bool ready = allow_lds(vocab_argmax_small_kernel, VS_LDS_BYTES);
+        if (!ready) return CAPDEC_EINVAL;
+        hipLaunchKernelGGL(vocab_argmax_small_kernel, dim3(nt), dim3(512), VS_LDS_BYTES, s, W, x, ldx, bias, V, M, K, out_a,
                            static_cast<int*>(out_b), nt, rows_dev);
         CAPDEC_LAUNCH_CHECK();
         return 0;

@@ -142,9 +142,10 @@ def test_attention_shapes(ops, B, H, Tq, Tk, dk):
 
 def test_vocab_argmax_and_nll(ops):
     g = torch.Generator().manual_seed(11)
-    # (up to 32 rows with K a multiple of 8: the eight-wavefront small-batch kernel; K = 132: the general one)
+    # (up to 32 rows with K a multiple of 32: the eight-wavefront small-batch kernel, with one to four of its k-groups
+    #  at work; other K: the general one)
     for M, V, K in ((5, 50, 64), (300, 10000, 512), (64, 5000, 512), (1024, 777, 128), (32, 5000, 512), (17, 777, 136),
-                    (1, 10000, 512), (32, 333, 8), (9, 130, 132)):
+                    (1, 10000, 512), (32, 333, 8), (9, 130, 132), (20, 300, 32), (32, 130, 96), (31, 4097, 160)):
         x = torch.randn(M, K, generator=g)
         W = torch.randn(V, K, generator=g) / K ** 0.5
         b = torch.randn(V, generator=g) * 0.1
