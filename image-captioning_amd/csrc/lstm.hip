@@ -386,6 +386,108 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmArgs a) {
     }
 }
 
+// The same tiling with whole-line loads (E and Hd multiples of 32): a load instruction of the kernel above touches 32
+// rows, 32 bytes of each, and the lines the wavefronts hold open compete for the 32 KiB vector cache.  Here a wavefront
+// fetches its 32 x 32 blocks of the samples and of the weights eight lanes per 128-byte row segment and turns them into
+// MFMA fragments through a private LDS region (rows padded to 36 floats: the 16-byte fragment reads of 16 lanes fall on
+// distinct banks); still no workgroup barrier in the loop.
+constexpr int LS_LD = 36;
+
+__global__ __launch_bounds__(256) void lstm_step_small_lds_kernel(LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) float stage[4][2 * 32 * LS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int u0 = blockIdx.x * 8;
+    const int nbx = a.E / 32, nbh = a.h0 ? a.Hd / 32 : 0, nb = nbx + nbh;  // 32-float blocks of the contraction
+    const int per = (nb + 3) / 4;
+    const int b0 = wave * per, b1 = min(nb, b0 + per);
+    float* sa = stage[wave];                                 // [32][LS_LD] samples
+    float* sw = sa + 32 * LS_LD;                             // [32][LS_LD] weight rows (gate, unit)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const float* xg[4];
+    const float* hg[4];
+    const float* wxg[4];
+    const float* whg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + lrow;
+        const int arow = min(row, a.B - 1);                  // rows past the batch repeat the last one: never stored
+        const int wrow = (row >> 3) * a.Hd + min(u0 + (row & 7), a.Hd - 1);
+        xg[i] = a.x + (int64_t)arow * a.ldx + 4 * lslot;
+        hg[i] = a.h0 ? a.h0 + (int64_t)arow * a.ldh0 + 4 * lslot : nullptr;
+        wxg[i] = a.w_ih + (int64_t)wrow * a.E + 4 * lslot;
+        whg[i] = a.w_hh + (int64_t)wrow * a.Hd + 4 * lslot;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4 ar[2][4], wr[2][4];
+    auto fetch = [&](int set, int b) {
+        if (b >= b1) return;
+        if (b < nbx) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ar[set][i] = *reinterpret_cast<const f32x4*>(xg[i] + 32 * b);
+                wr[set][i] = *reinterpret_cast<const f32x4*>(wxg[i] + 32 * b);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ar[set][i] = *reinterpret_cast<const f32x4*>(hg[i] + 32 * (b - nbx));
+                wr[set][i] = *reinterpret_cast<const f32x4*>(whg[i] + 32 * (b - nbx));
+            }
+        }
+    };
+    auto consume = [&](int set, int b) {
+        if (b >= b1) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(sa + (8 * i + lrow) * LS_LD + 4 * lslot) = ar[set][i];
+            *reinterpret_cast<f32x4*>(sw + (8 * i + lrow) * LS_LD + 4 * lslot) = wr[set][i];
+        }
+        // LDS serves one wavefront's accesses in order: the block written above is what the reads below see
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(sa + r * LS_LD + 8 * c + 4 * h);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(sw + r * LS_LD + 8 * c + 4 * h);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[m], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    fetch(0, b0);
+    for (int b = b0; b < b1; b += 2) {
+        fetch(1, b + 1);
+        consume(0, b);
+        fetch(0, b + 2);
+        consume(1, b + 1);
+    }
+    // partial tiles: each wavefront's own staging region holds its 16 x 64 values
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sa[e * 64 + lane] = acc[e];
+    __syncthreads();
+    // thread -> (sample i, unit ul); gate g of that pair sits in register e(i), lane 32 * h(i) + 8 * g + ul of every partial
+    const int i = tid >> 3, ul = tid & 7, u = u0 + ul;
+    if (i >= a.B || u >= a.Hd) return;
+    const int e = (i & 3) + 4 * (i >> 3), hl = ((i >> 2) & 1) * 32 + ul;
+    float gate[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int o = e * 64 + hl + 8 * g;
+        gate[g] = ((stage[0][o] + stage[1][o]) + (stage[2][o] + stage[3][o])) + (a.b_ih[g * a.Hd + u] + a.b_hh[g * a.Hd + u]);
+    }
+    const float cp = a.c0 ? a.c0[(int64_t)i * a.Hd + u] : 0.f;
+    const float cn = sigmoidf_(gate[1]) * cp + sigmoidf_(gate[0]) * tanhf(gate[2]);
+    const float hn = sigmoidf_(gate[3]) * tanhf(cn);
+    a.c1[(int64_t)i * a.Hd + u] = cn;
+    a.h1[(int64_t)i * a.ldh1 + u] = hn;
+    if (a.gates) {
+        float* gp = a.gates + (int64_t)i * 4 * a.Hd + u;
+        gp[0] = gate[0]; gp[a.Hd] = gate[1]; gp[2 * a.Hd] = gate[2]; gp[3 * a.Hd] = gate[3];
+    }
+}
+
 struct LstmBwdArgs {
     const float* gates; const float* c0; const float* c1;
     const float* dh_out; int64_t lddh; const float* dh_rec; const float* dc_in;
@@ -418,13 +520,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs a) {
     a.dc0[idx] = dc * sf;
 }
 
-CAPDEC_HOOK_VAR(g_lstm_staging);   // 0: automatic; 1: always the register-staged kernel (tests compare the two)
+// 0: automatic; 1: always the register-staged kernel; 2: small batches keep the fragments-from-memory kernel (tests
+// compare the forms)
+CAPDEC_HOOK_VAR(g_lstm_staging);
 
 }  // namespace
 
 #ifdef CAPDEC_TUNING_HOOKS
 extern "C" int capdec_lstm_force_staging(int mode) {
-    CAPDEC_REQUIRE(mode == 0 || mode == 1);
+    CAPDEC_REQUIRE(mode == 0 || mode == 1 || mode == 2);
     g_lstm_staging = mode;
     return 0;
 }
@@ -448,7 +552,10 @@ extern "C" int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, in
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
     if (!ready) return CAPDEC_EINVAL;
     if (B <= 32 && vec && E % 8 == 0 && Hd % 8 == 0 && g_lstm_staging != 1) {
-        hipLaunchKernelGGL(lstm_step_small_kernel, dim3(Hd / 8), dim3(256), 0, (hipStream_t)stream, a);
+        if (E % 32 == 0 && Hd % 32 == 0 && g_lstm_staging != 2)
+            hipLaunchKernelGGL(lstm_step_small_lds_kernel, dim3(Hd / 8), dim3(256), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(lstm_step_small_kernel, dim3(Hd / 8), dim3(256), 0, (hipStream_t)stream, a);
         CAPDEC_LAUNCH_CHECK();
         return 0;
     }

@@ -17,9 +17,11 @@ extern "C" {
 /* contraction tiles: 0 = automatic, 11 / 116 = 64x64 (BK 32 / 16), 22 / 216 = 128x128 (BK 32 / 16), 32 / 316 = 32x64 tile
  * with its k-loop split over the two wave pairs (BK 32 / 16) */
 int capdec_gemm_force_config(int cfg);
-/* 0 = automatic, 1 = operand tiles always staged through registers (never loaded straight into LDS) */
+/* 0 = automatic, 1 = operand tiles always staged through registers (never loaded straight into LDS; also keeps
+ * batches of at most 32 rows of the vocabulary arg-max on the general kernel) */
 int capdec_gemm_force_staging(int mode);
-/* the same choice for the LSTM step kernel */
+/* the same choice for the LSTM step kernel; 2 = batches of at most 32 samples keep the kernel that reads its MFMA
+ * fragments straight from memory (E and Hd multiples of 32 normally take the one with whole-line loads) */
 int capdec_lstm_force_staging(int mode);
 /* non-zero: attention backward always takes the general two-pass kernels (sequences up to 64 positions normally take a
  * one-pass kernel that keeps a (batch, head) slice in LDS) */

@@ -292,7 +292,8 @@ def test_f10_medium_decoder_default_init():
     check_greedy(ids_to_lists(ids, lengths), cpu_sd(dec), t(fx["enc"]), 4, 8, want_rows=unpad(fx["greedy_ids"]))
 
 
-@pytest.mark.parametrize("B,E,Hd", [(1, 256, 512), (7, 64, 96), (32, 256, 512), (32, 1024, 512), (20, 8, 8), (31, 40, 24)])
+@pytest.mark.parametrize("B,E,Hd", [(1, 256, 512), (7, 64, 96), (32, 256, 512), (32, 1024, 512), (20, 8, 8), (31, 40, 24), (9, 32, 32),
+                                    (32, 96, 160)])
 def test_lstm_step_small_batch_kernel(ops, B, E, Hd, tuning_lib):
     """Up to 32 samples (the CNN-RNN decode as the reference runs it, batch 32) take the kernel that gives a workgroup 8
     hidden units and splits the contraction over its wavefronts: against the fp64 cell equations (cnnrnn_model.py:17,
@@ -325,6 +326,16 @@ def test_lstm_step_small_batch_kernel(ops, B, E, Hd, tuning_lib):
         lib.capdec_lstm_force_staging(0)
     close(h1, h1b.cpu().numpy(), rtol=1e-5, what="h, small against large-batch kernel")
     close(gt, gtb.cpu().numpy(), rtol=1e-5, what="gates, small against large-batch kernel")
+    if E % 32 == 0 and Hd % 32 == 0:
+        # whole-line loads through wavefront-private LDS against fragments read straight from memory: the same products
+        # added in the same order within a 32-float block, the blocks in the same order
+        try:
+            lib.capdec_lstm_force_staging(2)
+            h1c, c1c, gtc = ops.lstm_step(*args, want_gates=True)
+        finally:
+            lib.capdec_lstm_force_staging(0)
+        close(h1, h1c.cpu().numpy(), rtol=1e-6, what="h, the two small-batch kernels")
+        close(gt, gtc.cpu().numpy(), rtol=1e-6, what="gates, the two small-batch kernels")
 
 
 # ---------------------------------------------------------------------------------------------
