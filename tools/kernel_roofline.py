@@ -132,7 +132,7 @@ def main():
     mfma("lstm_step_kernel (gates + cell)", "B=1024,E=256,Hd=512", 2.0 * Br * (Er + Hd) * 4 * Hd,
          lambda: ops.lstm_step(xr, h0, c0, wih, whh, bih, bhh))
     x32, h32, c32 = rnd(32, Er), rnd(32, Hd), rnd(32, Hd)
-    mfma("lstm_step_small_kernel (gates + cell, batch 32)", "B=32,E=256,Hd=512", 2.0 * 32 * (Er + Hd) * 4 * Hd,
+    mfma("lstm_step_small_lds_kernel (gates + cell, batch 32)", "B=32,E=256,Hd=512", 2.0 * 32 * (Er + Hd) * 4 * Hd,
          lambda: ops.lstm_step(x32, h32, c32, wih, whh, bih, bhh))
     Wv5, bv5, x5 = rnd(5000, Hd), rnd(5000), rnd(32, Hd)
     mfma("vocab_argmax_small_kernel + merge (batch 32, V=5000)", "32x5000x512", 2.0 * 32 * 5000 * Hd, lambda: ops.vocab_argmax(x5, Wv5, bv5))
