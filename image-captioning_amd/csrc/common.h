@@ -77,6 +77,10 @@ int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int 
 // tiles: the partials of rows beyond it are left untouched)
 int capdec_launch_vocab_argmax_rows(const float* x, int64_t ldx, const float* W, const float* bias, int M, int V, int K,
                                     float* part_val, int32_t* part_idx, const int32_t* rows_dev, hipStream_t s);
+// capdec_lstm_step that does nothing when live[0] is zero (nullable device scalar)
+int capdec_launch_lstm_step(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, const float* w_ih,
+                            const float* w_hh, const float* b_ih, const float* b_hh, int B, int E, int Hd, float* h1,
+                            int64_t ldh1, float* c1, float* gates_out, const int32_t* live, hipStream_t stream);
 int capdec_launch_layernorm_rows(const float* x, const float* add, int add_div, const int32_t* add_map,
                                  const float* gamma, const float* beta, float eps, int Mcap, int E, float* y,
                                  const int32_t* rows_dev, hipStream_t s, const float* gamma2 = nullptr,

@@ -28,8 +28,14 @@ struct Carver {
 
 // ---- bookkeeping kernels ------------------------------------------------------------------------
 __global__ void greedy_init_kernel(int32_t* tok, int64_t ldtok, int32_t* done, int64_t* out_ids, int32_t* out_len,
-                                   int32_t* dirty, int B, int max_len, int sos) {
+                                   int32_t* dirty, int B, int max_len, int sos, int32_t* fin = nullptr,
+                                   int32_t* live = nullptr) {
     const int n = B * max_len;
+    if (fin)      // per-step finish counts and row counts of a loop that ends on the device (greedy_advance_kernel)
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= max_len; t += gridDim.x * blockDim.x) {
+            if (t < max_len) fin[t] = 0;
+            live[t] = B;
+        }
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) out_ids[idx] = -1;
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
         tok[(int64_t)b * ldtok] = sos;
@@ -48,9 +54,23 @@ __global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __rest
                                                              int64_t* out_ids, int32_t* out_len, int32_t* dirty,
                                                              const float* __restrict__ emb,
                                                              const float* __restrict__ pe, int E, int V,
-                                                             float* __restrict__ x_next, int64_t ldx_next = 0) {
+                                                             float* __restrict__ x_next, int64_t ldx_next = 0,
+                                                             int32_t* fin = nullptr, int32_t* live_next = nullptr) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (fin) {
+        // fin[s]: captions whose <EOS> came at step s.  Once all B finished in the steps before this one (counts no
+        // workgroup of this launch changes) nothing is recorded any more and the next step's kernels find a row count
+        // of zero: the reference's "all done" exit (cnnrnn_model.py:101-103) without a host synchronisation.
+        int fin_before = 0;
+        for (int s = lane; s < t; s += 64) fin_before += fin[s];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) fin_before += __shfl_xor(fin_before, o, 64);
+        if (fin_before >= B) {
+            if (blockIdx.x == 0 && threadIdx.x == 0 && live_next) live_next[0] = 0;
+            return;
+        }
+    }
     if (b >= B) return;
     float v = -INFINITY;
     int i = INT_MAX;
@@ -62,6 +82,7 @@ __global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __rest
         if (!done[b]) {
             if (i == eos) {
                 done[b] = 1;
+                if (fin) atomicAdd(&fin[t], 1);
             } else {
                 const int n = out_len[b];
                 out_ids[(int64_t)b * max_len + n] = i;
@@ -1150,6 +1171,7 @@ struct RnnWs {
     float *x, *h[2], *c[2];
     float* pval; int32_t* pidx;
     int32_t *tok, *done;
+    int32_t *fin, *live;     // [max_len], [max_len + 1]: see greedy_advance_kernel
 };
 
 static size_t carve_rnn(const capdec_rnn_model* m, int B, int max_len, void* base, RnnWs* w) {
@@ -1165,6 +1187,8 @@ static size_t carve_rnn(const capdec_rnn_model* m, int B, int max_len, void* bas
     d.pidx = c.take<int32_t>(capdec_part_elems(B, (int)nt));
     d.tok = c.take<int32_t>((size_t)B * (max_len + 1));
     d.done = c.take<int32_t>((size_t)B);
+    d.fin = c.take<int32_t>((size_t)max_len);
+    d.live = c.take<int32_t>((size_t)max_len + 1);
     if (w) *w = d;
     return c.off;
 }
@@ -1193,7 +1217,7 @@ int capdec_rnn_greedy_decode(const capdec_rnn_model* m, const float* x0, int B, 
     const int E = m->E, Hd = m->Hd, V = m->V;
     const int64_t ldtok = max_len + 1;
     hipLaunchKernelGGL(greedy_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, out_ids, out_len,
-                       (int32_t*)nullptr, B, max_len, sos);
+                       (int32_t*)nullptr, B, max_len, sos, w.fin, w.live);
     CAPDEC_LAUNCH_CHECK();
     // the image is time-step 0 of the LSTM, from the zero state (cnnrnn_model.py:75)
     CAPDEC_TRY(capdec_lstm_step(x0, E, nullptr, 0, nullptr, m->w_ih, m->w_hh, m->b_ih, m->b_hh, B, E, Hd, w.h[0], Hd,
@@ -1202,14 +1226,16 @@ int capdec_rnn_greedy_decode(const capdec_rnn_model* m, const float* x0, int B, 
     const int nt = capdec_vocab_tiles(V);
     int cur = 0;
     for (int t = 0; t < max_len; ++t) {
-        CAPDEC_TRY(capdec_lstm_step(w.x, E, w.h[cur], Hd, w.c[cur], m->w_ih, m->w_hh, m->b_ih, m->b_hh, B, E, Hd,
-                                    w.h[cur ^ 1], Hd, w.c[cur ^ 1], nullptr, stream));
+        // (w.live[t]: B, or zero once every caption has finished; every kernel of the step reads it first)
+        CAPDEC_TRY(capdec_launch_lstm_step(w.x, E, w.h[cur], Hd, w.c[cur], m->w_ih, m->w_hh, m->b_ih, m->b_hh, B, E, Hd,
+                                           w.h[cur ^ 1], Hd, w.c[cur ^ 1], nullptr, w.live + t, s));
         cur ^= 1;
-        CAPDEC_TRY(capdec_vocab_argmax_partial(w.h[cur], Hd, m->fc2_w, m->fc2_b, B, V, Hd, w.pval, w.pidx, stream));
+        CAPDEC_TRY(capdec_launch_vocab_argmax_rows(w.h[cur], Hd, m->fc2_w, m->fc2_b, B, V, Hd, w.pval, w.pidx, w.live + t, s));
         const bool last = (t + 1 == max_len);
         hipLaunchKernelGGL(greedy_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
                            eos, w.tok, ldtok, w.done, out_ids, out_len, (int32_t*)nullptr, m->emb,
-                           (const float*)nullptr, E, V, last ? nullptr : w.x);
+                           (const float*)nullptr, E, V, last ? nullptr : w.x, (int64_t)0, w.fin,
+                           last ? nullptr : w.live + t + 1);
         CAPDEC_LAUNCH_CHECK();
     }
     return 0;

@@ -44,10 +44,12 @@ struct LstmArgs {
     const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh;
     int B, E, Hd;
     float* h1; int64_t ldh1; float* c1; float* gates;
+    const int32_t* live;     // nullable device scalar: zero = a decode loop whose captions have all finished: nothing to do
 };
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
+    if (a.live && a.live[0] <= 0) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ps = lds;                       // [2][TB][LDK]
     float* Qs = lds + 2 * TB * LDK;        // [2][4*TU][LDK], row = gate*TU + local unit
@@ -177,6 +179,7 @@ static_assert(DROWS % 32 == 0 && 2 * DNPW <= 63, "tile does not cut into pieces"
 __device__ __forceinline__ int lstm_swz(int row) { return (row >> 1) & 7; }
 
 __global__ __launch_bounds__(256) void lstm_step_dma_kernel(LstmArgs a) {
+    if (a.live && a.live[0] <= 0) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -309,6 +312,7 @@ __global__ __launch_bounds__(256) void lstm_step_dma_kernel(LstmArgs a) {
 // staging); the partial tiles meet in LDS, where one thread per (sample, unit) adds them and applies the cell update.
 // Hd/8 workgroups (64 at Hd = 512), 192 MFMAs per wavefront.
 __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmArgs a) {
+    if (a.live && a.live[0] <= 0) return;
     __shared__ float red[4][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmArgs a) {
 constexpr int LS_LD = 36;
 
 __global__ __launch_bounds__(256) void lstm_step_small_lds_kernel(LstmArgs a) {
+    if (a.live && a.live[0] <= 0) return;
     __shared__ __attribute__((aligned(16))) float stage[4][2 * 32 * LS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -537,11 +542,18 @@ extern "C" int capdec_lstm_force_staging(int mode) {
 extern "C" int capdec_lstm_step(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, const float* w_ih,
                                 const float* w_hh, const float* b_ih, const float* b_hh, int B, int E, int Hd,
                                 float* h1, int64_t ldh1, float* c1, float* gates_out, void* stream) {
+    return capdec_launch_lstm_step(x, ldx, h0, ldh0, c0, w_ih, w_hh, b_ih, b_hh, B, E, Hd, h1, ldh1, c1, gates_out, nullptr,
+                                   (hipStream_t)stream);
+}
+
+int capdec_launch_lstm_step(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, const float* w_ih,
+                            const float* w_hh, const float* b_ih, const float* b_hh, int B, int E, int Hd, float* h1,
+                            int64_t ldh1, float* c1, float* gates_out, const int32_t* live, hipStream_t stream) {
     CAPDEC_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && h1 && c1 && B >= 0 && E >= 1 && Hd >= 1);
     CAPDEC_REQUIRE(ldx >= E && ldh1 >= Hd && (!h0 || ldh0 >= Hd));
     CAPDEC_REQUIRE(h1 != h0 && c1 != c0);   // other workgroups still read the old state
     if (B == 0) return 0;
-    LstmArgs a{x, ldx, h0, ldh0, c0, w_ih, w_hh, b_ih, b_hh, B, E, Hd, h1, ldh1, c1, gates_out};
+    LstmArgs a{x, ldx, h0, ldh0, c0, w_ih, w_hh, b_ih, b_hh, B, E, Hd, h1, ldh1, c1, gates_out, live};
     const bool vec = E % 4 == 0 && Hd % 4 == 0 && ldx % 4 == 0 && capdec_aligned16(x) && capdec_aligned16(w_ih) &&
                      capdec_aligned16(w_hh) && (!h0 || (capdec_aligned16(h0) && ldh0 % 4 == 0));
     constexpr size_t smem = LSTM_LDS_FLOATS * sizeof(float);

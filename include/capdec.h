@@ -498,7 +498,9 @@ typedef struct capdec_rnn_model {
 } capdec_rnn_model;
 
 size_t capdec_rnn_decode_workspace_bytes(const capdec_rnn_model* m, int B, int max_len);
-/* x0 [B,E] is the BatchNorm'ed image projection (time-step 0 of the LSTM, zero initial state). */
+/* x0 [B,E] is the BatchNorm'ed image projection (time-step 0 of the LSTM, zero initial state).
+ * Greedy decode (cnnrnn_model.py:57-110): all max_len steps are enqueued without a host sync; the reference's exit
+ * once every caption holds an <EOS> (:101-103) is taken on the device, as in capdec_tf_greedy_decode. */
 int capdec_rnn_greedy_decode(const capdec_rnn_model* m, const float* x0, int B, int max_len, int sos, int eos,
                              void* workspace, size_t workspace_bytes, int64_t* out_ids, int32_t* out_len,
                              void* stream);

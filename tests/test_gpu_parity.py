@@ -595,6 +595,59 @@ def test_f7_cnn_rnn_eval_logits_and_greedy():
     assert ids_to_lists(ids, lengths) == unpad(fx["greedy_ids"])
 
 
+def test_cnn_rnn_greedy_loop_ends_on_the_device_once_every_caption_has_finished():
+    """cnnrnn_model.py:101-103 leaves the loop when every caption holds an <EOS>.  The decoder enqueues all max_length
+    steps; once all captions have finished, the later steps' kernels find a row count of zero.  Same tokens as with the
+    loop run to the end (an <EOS> id that never occurs), same tokens as the oracle's restatement of the reference loop,
+    in less time.  Batch 32 (the small-batch kernels) and 96 (the general ones)."""
+    import time
+    from capdec.engine import rnn_greedy_ids
+    from models.cnnrnn_model import CNNtoRNN
+    E, Hd, V, ML = 256, 512, 5000, 40
+    torch.manual_seed(4)
+    m = CNNtoRNN(E, Hd, V).eval()
+    with torch.no_grad():
+        m.decoderRNN.fc2.bias[R.EOS] += 0.12       # default-init logits: the largest of 5000 is about 0.15-0.2
+    sd = {k[len("decoderRNN."):]: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda()
+    rnn = m.decoderRNN
+    g = torch.Generator().manual_seed(6)
+    pool = torch.rand(512, 2048, generator=g)
+    with torch.no_grad():
+        x_pool = rnn.image_input(pool.cuda())
+    # rows that finish within 25 steps (a caption does not depend on the rest of the batch)
+    _, lens0 = rnn_greedy_ids(rnn, x_pool, ML, R.SOS, R.EOS)
+    keep = torch.nonzero(lens0 < 25).flatten()
+    assert keep.numel() >= 96 and int(lens0[keep].max()) >= 2, (keep.numel(), lens0[keep].max())
+    for B in (32, 96):
+        rows = keep[:B]
+        feats, x0 = pool[rows], x_pool[rows.cuda()].contiguous()
+        want = R.cnnrnn_greedy_ids(sd, feats, ML)
+
+        def timed(eos):
+            best = None
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = rnn_greedy_ids(rnn, x0, ML, R.SOS, eos)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            return out, best
+
+        (ids, lens), dt = timed(R.EOS)
+        (ids_full, lens_full), dt_full = timed(V + 7)
+        lens_l = lens.tolist()
+        assert max(lens_l) < 25 and min(lens_full.tolist()) == ML
+        got = [row[:n] for row, n in zip(ids.tolist(), lens_l)]
+        assert got == want
+        for b in range(B):
+            assert ids_full[b, :lens_l[b]].tolist() == got[b] and int(ids_full[b, lens_l[b]]) == R.EOS
+        print(f"CNN-RNN early exit, batch {B}: longest caption {max(lens_l)} of {ML} steps, "
+              f"{dt * 1e3:.3f} ms against {dt_full * 1e3:.3f} ms")
+        assert dt < dt_full
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE-sized workloads: size-independent properties + oracle on a row subset
 # ---------------------------------------------------------------------------------------------
