@@ -229,6 +229,44 @@ def decode_variant(kind, device, steps, warmup):
                        else "is a plain launch")}
 
 
+def early_exit_variant(device, reps=6):
+    """cfg2 shapes at the reference's default max_length of 50 (cnnattn_model.py:34) on captions that all END: the
+    <EOS> bias of the random decoder is raised until a caption ends within a few steps, and the batch is drawn from
+    the rows that finish within 30 (a caption does not depend on the rest of its batch).  The reference leaves its
+    loop when every caption has finished (transformer.py:166-168); the cached decoder does so on the device.  Timed
+    against the same batch with an <EOS> id that never occurs (all 50 steps run in full)."""
+    from capdec import engine
+    model = build_model(device)
+    with torch.no_grad():
+        model.fc2.bias[2] += 1.9
+    g = torch.Generator().manual_seed(77)
+    pool = torch.rand(B + B // 4, D, generator=g).to(device)
+    ML = 50
+    with torch.no_grad():
+        enc_pool = model.encode_features(pool, "precomputed")
+        _, lens0 = model.greedy_ids(enc_pool, 1, 2, ML)
+        keep = torch.nonzero(lens0 < 30).flatten()[:B]
+        enc = enc_pool[keep.to(device)].contiguous()
+
+        def timed(eos):
+            model.greedy_ids(enc, 1, eos, ML)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                out = model.greedy_ids(enc, 1, eos, ML)
+            torch.cuda.synchronize()
+            return out, (time.perf_counter() - t0) / reps
+
+        (_, lens), dt = timed(2)
+        _, dt_full = timed(V + 7)
+    n = int(enc.shape[0])
+    return {"workload": f"cfg2 CNN-Attn greedy decode at the reference's default max_length {ML}, B={n}, captions that "
+                        f"end (longest {int(lens.max())} tokens, mean {float(lens.float().mean()):.1f}): the loop ends on "
+                        "the device once every caption has its <EOS>",
+            "value": n / dt, "unit": "captions/s", "ms_per_step": dt * 1e3,
+            "ms_per_step_all_50_steps": dt_full * 1e3}
+
+
 def cnn_rnn_variant(device, reps=50):
     """BASELINE.json configs[0]: CNN-RNN greedy decode, B=32, len 20, E=256, hidden 512, V=5000 (cnnrnn_model.py:57-110):
     the HIP path on the GPU, and the oracle's restatement of the reference loop on this host's CPU cores."""
@@ -418,6 +456,8 @@ def variants_bench(device, steps=6, warmup=2):
     out["cfg5_shard"] = decode_variant("yolocnn", device, steps, warmup)
     # ---- BASELINE.json configs[0]: CNN-RNN greedy, B=32, on the GPU and (the configuration as worded) on the CPU ----
     out["cfg1_cnn_rnn_b32"] = cnn_rnn_variant(device)
+    # ---- cfg2 at the reference's default max_length 50 on captions that end: the device-side end of the loop ----
+    out["decode_maxlen50_captions_that_end"] = early_exit_variant(device)
     # ---- decode, S=64 grid: per-cell Linear(2048,E) (+ folded BatchNorm) then the cached greedy decoder ----
     model = build_model(device)
     S = 64
