@@ -729,13 +729,16 @@ __global__ __launch_bounds__(128 * WM) void bgemm_kernel(BgemmKArgs k) {
 
 // Second stage of the fixed-order split-K: C[i,j] = epi(ws[0][i][j] + ws[1][i][j] + ... ) with the slabs added in
 // index order by one thread per element, so the sum does not depend on which workgroup finished first.
+// [k_tail0, k_tail1): the last few k of a contraction whose length is not a whole number of k-tiles (both operands
+// k-contiguous), left out of the slabs so that the first stage reads whole tiles only; added here, last.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, capdec_gemm_group g,
-                                                            int relu) {
+                                                            int relu, int k_tail0, int k_tail1) {
     const int64_t n = (int64_t)g.I * g.J;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(idx / g.J), j = (int)(idx - (int64_t)i * g.J);
         float v = ws[idx];
         for (int sp = 1; sp < nsplit; ++sp) v += ws[(int64_t)sp * n + idx];
+        for (int k = k_tail0; k < k_tail1; ++k) v += g.P[(int64_t)i * g.ldp + k] * g.Q[(int64_t)j * g.ldq + k];
         if (g.bias_j) v += g.bias_j[j];
         if (g.bias_i) v += g.bias_i[i];
         if (g.scale_j) v = v * g.scale_j[j] + g.shift_j[j];
@@ -1179,6 +1182,12 @@ int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int 
                        !a.x.k_dev && a.x.splitk_ws);
         if ((size_t)a.x.splitk_ws_elems < (size_t)g.I * g.J) return CAPDEC_ENOMEM;      // room for one slab at least
         a.flags = (flags & ~(CAPDEC_GEMM_SPLITK | CAPDEC_GEMM_RELU)) | CAPDEC_GEMM_ATOMIC;
+        // A long contraction that is not a whole number of 32-deep k-tiles (the YOLO feature is 86436 wide) would send
+        // every tile through the register-staged loads for the sake of its last one (930 against 800 us at
+        // 1024 x 512 x 86436): the first stage takes the whole tiles, the second adds the remaining k.
+        int k_main = K;
+        if (!tp && !tq && vec && K % 32 != 0 && K >= 4096) k_main = K / 32 * 32;
+        a.K = k_main;
         int rc;
         if (tp) rc = launch_gemm_layout<true, true>(a, 1, maxI, maxJ, vec, s);
         else if (tq) rc = launch_gemm_layout<false, true>(a, 1, maxI, maxJ, vec, s);
@@ -1188,7 +1197,7 @@ int capdec_launch_gemm(const capdec_gemm_group* groups, int ngroups, int K, int 
         const int64_t n = (int64_t)g.I * g.J;
         const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.x.splitk_ws, nsplit, g,
-                           (flags & CAPDEC_GEMM_RELU) ? 1 : 0);
+                           (flags & CAPDEC_GEMM_RELU) ? 1 : 0, k_main, K);
         CAPDEC_LAUNCH_CHECK();
         return 0;
     }

@@ -47,6 +47,25 @@ def test_gemm_plain_and_epilogues(ops, M, N, K):
           (ref + b.double()) * sc.double() + sh.double(), what="scale/shift")
 
 
+@pytest.mark.parametrize("M,N,K", [(33, 64, 4100), (100, 40, 5003 * 4), (64, 64, 4096), (7, 5, 4097 * 4 + 28)])
+def test_gemm_fixed_order_split_with_a_ragged_last_k_tile(ops, M, N, K):
+    """Long contractions split over workgroups with their partial sums added in a fixed order: when K is not a whole
+    number of 32-deep tiles the first stage takes the whole tiles and the second stage adds the remaining k.  Against
+    fp64, with the epilogue (bias, scale / shift, residual), and bit for bit from run to run."""
+    g = torch.Generator().manual_seed(K + M)
+    x = torch.randn(M, K + 8, generator=g)[:, :K]            # a strided view, as the feature heads pass
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b, sc, sh = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = (x.double() @ W.double().t() + b.double()) * sc.double() + sh.double() + res.double()
+    args = (x.cuda(), W.cuda(), b.cuda())
+    kw = dict(scale=sc.cuda(), shift=sh.cuda(), residual=res.cuda(), split_k=True)
+    y = ops.linear(*args, **kw)
+    close(y, ref)
+    assert torch.equal(y, ops.linear(*args, **kw))
+    close(ops.linear(args[0], args[1], split_k=True), x.double() @ W.double().t(), what="plain")
+
+
 def test_gemm_strided_views_and_groups(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(50, 300, generator=g).cuda()
