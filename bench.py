@@ -457,7 +457,10 @@ def variants_bench(device, steps=6, warmup=2):
     # ---- BASELINE.json configs[0]: CNN-RNN greedy, B=32, on the GPU and (the configuration as worded) on the CPU ----
     out["cfg1_cnn_rnn_b32"] = cnn_rnn_variant(device)
     # ---- cfg2 at the reference's default max_length 50 on captions that end: the device-side end of the loop ----
-    out["decode_maxlen50_captions_that_end"] = early_exit_variant(device)
+    try:
+        out["decode_maxlen50_captions_that_end"] = early_exit_variant(device)
+    except Exception as e:                           # a side measurement: never at the cost of the ones after it
+        out["decode_maxlen50_captions_that_end"] = {"error": f"{type(e).__name__}: {e}"}
     # ---- decode, S=64 grid: per-cell Linear(2048,E) (+ folded BatchNorm) then the cached greedy decoder ----
     model = build_model(device)
     S = 64
