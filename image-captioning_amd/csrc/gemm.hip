@@ -849,7 +849,8 @@ __global__ __launch_bounds__(256, 5) void vocab_reduce_kernel(const float* __res
     }
 }
 
-// ---- vocabulary arg-max for batches of at most 32 rows (the reference's own decode runs at batch 32) --------------
+// ---- vocabulary arg-max for small batches: blocks of 32 rows, at most eight (the reference's loaders default to
+// batches of 32 and 64) -------------------------------------------------------------------------------------------
 // The tiling above gives such a batch V/64 workgroups whose wavefronts each walk the whole contraction for a 64-row
 // tile that is half empty: 18.6 us at 32 x 5000 x 512, a tenth of it arithmetic.  Here a workgroup of eight wavefronts
 // owns one 64-id vocabulary tile (the same tile numbering, so the partial-result layout is unchanged): two wavefronts
@@ -861,6 +862,7 @@ __global__ __launch_bounds__(256, 5) void vocab_reduce_kernel(const float* __res
 // rows per load instruction - ran at 13.3 us: the lines eight wavefronts hold open overflow the 32 KiB vector cache.)
 // Vocabulary ids on the accumulator registers, rows on the lanes, as above.  K must be a multiple of 32.
 constexpr int VS_LD = 36;                                   // floats per staged row
+constexpr int VS_MAX_ROWS = 256;                            // larger batches take the general tiling
 constexpr int VS_WAVE_FLOATS = 2 * 32 * VS_LD;              // W block + x block of one wavefront
 constexpr size_t VS_LDS_BYTES = (size_t)8 * VS_WAVE_FLOATS * sizeof(float);
 
@@ -872,7 +874,8 @@ __global__ __launch_bounds__(512) void vocab_argmax_small_kernel(const float* __
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float sm_v[2][32];
     __shared__ int sm_i[2][32];
-    if (rows_dev && rows_dev[0] <= 0) return;
+    const int j0 = 32 * blockIdx.y;                          // first row of this workgroup's block of 32
+    if (rows_dev && j0 >= rows_dev[0]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wv = wave & 1, wk = wave >> 1;
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(512) void vocab_argmax_small_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         wg[i] = W + (int64_t)min(i0 + 8 * i + lrow, V - 1) * K + 4 * lslot;    // ids past the vocabulary repeat the last one
-        xg[i] = x + (int64_t)min(8 * i + lrow, M - 1) * ldx + 4 * lslot;       // rows past the batch likewise: never stored
+        xg[i] = x + (int64_t)min(j0 + 8 * i + lrow, M - 1) * ldx + 4 * lslot;  // rows past the batch likewise: never stored
     }
     f32x16 acc;
 #pragma unroll
@@ -960,11 +963,11 @@ __global__ __launch_bounds__(512) void vocab_argmax_small_kernel(const float* __
         }
     }
     __syncthreads();
-    if (tid < 32 && tid < M) {
+    if (tid < 32 && j0 + tid < M) {
         float a0 = sm_v[0][tid];
         int bb = sm_i[0][tid];
         argmax_merge(a0, bb, sm_v[1][tid], sm_i[1][tid]);
-        const int64_t o = capdec_part_off(tid, tile, ntiles);
+        const int64_t o = capdec_part_off(j0 + tid, tile, ntiles);
         out_val[o] = a0;
         out_idx[o] = bb;
     }
@@ -1281,11 +1284,12 @@ static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const floa
     if (M == 0) return 0;
     const int nt = capdec_vocab_tiles(V);
     const bool vec = (K % 4 == 0) && (ldx % 4 == 0) && capdec_aligned16(x) && capdec_aligned16(W);
-    if (mode == 0 && M <= 32 && vec && K % 32 == 0 && g_staging != 1) {
-        // a batch of at most 32 rows: one workgroup of eight wavefronts per vocabulary tile
+    if (mode == 0 && M <= VS_MAX_ROWS && vec && K % 32 == 0 && g_staging != 1) {
+        // a small batch (the reference's loaders default to 32 and 64 rows): one workgroup of eight wavefronts per
+        // vocabulary tile and block of 32 rows
         static const bool ready = allow_lds(vocab_argmax_small_kernel, VS_LDS_BYTES);
         if (!ready) return CAPDEC_EINVAL;
-        hipLaunchKernelGGL(vocab_argmax_small_kernel, dim3(nt), dim3(512), VS_LDS_BYTES, s, W, x, ldx, bias, V, M, K, out_a,
+        hipLaunchKernelGGL(vocab_argmax_small_kernel, dim3(nt, (M + 31) / 32), dim3(512), VS_LDS_BYTES, s, W, x, ldx, bias, V, M, K, out_a,
                            static_cast<int*>(out_b), nt, rows_dev);
         CAPDEC_LAUNCH_CHECK();
         return 0;

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(256) void lstm_step_small_lds_kernel(LstmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int u0 = blockIdx.x * 8;
+    const int s0 = 32 * blockIdx.y;                           // first sample of this workgroup's block of 32
     const int nbx = a.E / 32, nbh = a.h0 ? a.Hd / 32 : 0, nb = nbx + nbh;  // 32-float blocks of the contraction
     const int per = (nb + 3) / 4;
     const int b0 = wave * per, b1 = min(nb, b0 + per);
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void lstm_step_small_lds_kernel(LstmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 8 * i + lrow;
-        const int arow = min(row, a.B - 1);                  // rows past the batch repeat the last one: never stored
+        const int arow = min(s0 + row, a.B - 1);             // rows past the batch repeat the last one: never stored
         const int wrow = (row >> 3) * a.Hd + min(u0 + (row & 7), a.Hd - 1);
         xg[i] = a.x + (int64_t)arow * a.ldx + 4 * lslot;
         hg[i] = a.h0 ? a.h0 + (int64_t)arow * a.ldh0 + 4 * lslot : nullptr;
@@ -473,9 +474,10 @@ __global__ __launch_bounds__(256) void lstm_step_small_lds_kernel(LstmArgs a) {
     for (int e = 0; e < 16; ++e) sa[e * 64 + lane] = acc[e];
     __syncthreads();
     // thread -> (sample i, unit ul); gate g of that pair sits in register e(i), lane 32 * h(i) + 8 * g + ul of every partial
-    const int i = tid >> 3, ul = tid & 7, u = u0 + ul;
+    const int il = tid >> 3, ul = tid & 7, u = u0 + ul;      // il: sample within the block
+    const int i = s0 + il;
     if (i >= a.B || u >= a.Hd) return;
-    const int e = (i & 3) + 4 * (i >> 3), hl = ((i >> 2) & 1) * 32 + ul;
+    const int e = (il & 3) + 4 * (il >> 3), hl = ((il >> 2) & 1) * 32 + ul;
     float gate[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -563,11 +565,15 @@ int capdec_launch_lstm_step(const float* x, int64_t ldx, const float* h0, int64_
         hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
     if (!ready) return CAPDEC_EINVAL;
+    if (B <= 256 && vec && E % 32 == 0 && Hd % 32 == 0 && g_lstm_staging == 0) {
+        // small batches (the reference's loaders default to 32 and 64 samples): blocks of 32
+        hipLaunchKernelGGL(lstm_step_small_lds_kernel, dim3(Hd / 8, (B + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
     if (B <= 32 && vec && E % 8 == 0 && Hd % 8 == 0 && g_lstm_staging != 1) {
-        if (E % 32 == 0 && Hd % 32 == 0 && g_lstm_staging != 2)
-            hipLaunchKernelGGL(lstm_step_small_lds_kernel, dim3(Hd / 8), dim3(256), 0, (hipStream_t)stream, a);
-        else
-            hipLaunchKernelGGL(lstm_step_small_kernel, dim3(Hd / 8), dim3(256), 0, (hipStream_t)stream, a);
+        // widths that are multiples of 8 but not of 32 (or override 2): fragments read straight from memory
+        hipLaunchKernelGGL(lstm_step_small_kernel, dim3(Hd / 8), dim3(256), 0, (hipStream_t)stream, a);
         CAPDEC_LAUNCH_CHECK();
         return 0;
     }

@@ -189,17 +189,20 @@ def test_argmax_ties_resolve_to_lowest_index(ops):
     W[[17, 150, 299]] = 1.0      # three exactly equal winners in different tiles / lane halves
     idx, _ = ops.vocab_argmax(x, W.cuda(), torch.zeros(300).cuda())
     assert torch.all(idx.cpu() == 17)
-    idx, _ = ops.vocab_argmax(x[:29], W.cuda(), torch.zeros(300).cuda())       # the small-batch kernel
-    assert torch.all(idx.cpu() == 17)
+    W32 = torch.zeros(300, 32)                                   # K a multiple of 32: the small-batch kernel, one and two row blocks
+    W32[[17, 150, 299]] = 1.0
+    for m in (29, 47, 128, 256):
+        idx, _ = ops.vocab_argmax(torch.ones(m, 32).cuda(), W32.cuda(), torch.zeros(300).cuda())
+        assert torch.all(idx.cpu() == 17)
 
 
 def test_small_batch_vocab_argmax_against_the_general_kernel(ops):
-    """Batches of at most 32 rows take a kernel of their own (a workgroup of eight wavefronts per vocabulary tile, the
+    """Batches of at most 256 rows (blocks of 32) take a kernel of their own (a workgroup of eight wavefronts per vocabulary tile, the
     contraction split four ways); the tuning build's staging override sends the same call through the general kernel.
     Same winners (near-ties aside), values within rounding of each other."""
     from capdec import _lib
     g = torch.Generator().manual_seed(23)
-    for M, V, K in ((32, 5000, 512), (32, 10000, 512), (7, 1000, 256)):
+    for M, V, K in ((32, 5000, 512), (32, 10000, 512), (7, 1000, 256), (64, 5000, 512), (33, 1000, 256), (128, 5000, 512), (100, 10000, 512), (256, 5000, 512)):
         x = torch.randn(M, K, generator=g).cuda()
         W = (torch.randn(V, K, generator=g) / K ** 0.5).cuda()
         b = (torch.randn(V, generator=g) * 0.1).cuda()
@@ -250,7 +253,7 @@ def test_f9_lstm_step(ops):
     close(ca, cb, rtol=1e-6)
 
 
-@pytest.mark.parametrize("B,E,Hd", [(100, 256, 512), (33, 64, 96), (1024, 1024, 512)])
+@pytest.mark.parametrize("B,E,Hd", [(300, 256, 512), (257, 64, 96), (1024, 1024, 512)])
 def test_lstm_step_tiles_loaded_straight_into_lds(ops, B, E, Hd, tuning_lib):
     """E and Hd multiples of 32 take the kernel whose loads write LDS directly: against the fp64 cell equations
     (cnnrnn_model.py:17,29-30: nn.LSTM, gates i,f,g,o) and bit for bit against the register-staged kernel."""
@@ -312,10 +315,10 @@ def test_f10_medium_decoder_default_init():
 
 
 @pytest.mark.parametrize("B,E,Hd", [(1, 256, 512), (7, 64, 96), (32, 256, 512), (32, 1024, 512), (20, 8, 8), (31, 40, 24), (9, 32, 32),
-                                    (32, 96, 160)])
+                                    (32, 96, 160), (33, 256, 512), (64, 256, 512), (50, 64, 96), (128, 256, 512), (97, 32, 64), (256, 256, 512)])
 def test_lstm_step_small_batch_kernel(ops, B, E, Hd, tuning_lib):
-    """Up to 32 samples (the CNN-RNN decode as the reference runs it, batch 32) take the kernel that gives a workgroup 8
-    hidden units and splits the contraction over its wavefronts: against the fp64 cell equations (cnnrnn_model.py:17,
+    """Up to 256 samples (the reference's loaders default to batches of 32 and 64), in blocks of 32, take the kernels that
+    give a workgroup 8 hidden units and split the contraction over its wavefronts: against the fp64 cell equations (cnnrnn_model.py:17,
     29-30) and, within rounding, against the large-batch kernel."""
     lib = tuning_lib
     g = torch.Generator().manual_seed(B * 7 + E)
@@ -345,7 +348,7 @@ def test_lstm_step_small_batch_kernel(ops, B, E, Hd, tuning_lib):
         lib.capdec_lstm_force_staging(0)
     close(h1, h1b.cpu().numpy(), rtol=1e-5, what="h, small against large-batch kernel")
     close(gt, gtb.cpu().numpy(), rtol=1e-5, what="gates, small against large-batch kernel")
-    if E % 32 == 0 and Hd % 32 == 0:
+    if E % 32 == 0 and Hd % 32 == 0 and B <= 32:
         # whole-line loads through wavefront-private LDS against fragments read straight from memory: the same products
         # added in the same order within a 32-float block, the blocks in the same order
         try:
@@ -618,7 +621,7 @@ def test_cnn_rnn_greedy_loop_ends_on_the_device_once_every_caption_has_finished(
     """cnnrnn_model.py:101-103 leaves the loop when every caption holds an <EOS>.  The decoder enqueues all max_length
     steps; once all captions have finished, the later steps' kernels find a row count of zero.  Same tokens as with the
     loop run to the end (an <EOS> id that never occurs), same tokens as the oracle's restatement of the reference loop,
-    in less time.  Batch 32 (the small-batch kernels) and 96 (the general ones)."""
+    in less time.  Batches of 32 and 96 (one and three blocks of the small-batch kernels)."""
     import time
     from capdec.engine import rnn_greedy_ids
     from models.cnnrnn_model import CNNtoRNN
