@@ -295,8 +295,21 @@ def cnn_rnn_variant(device, reps=50):
         m.caption_ids(fd, max_length=LEN)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    # the same decode at the other batch sizes of the reference's loaders and drivers (get_loader.py:203, train.py:28)
+    other = {}
+    for b2 in (64, 256):
+        f2 = torch.rand(b2, D, generator=g).to(device)
+        for _ in range(5):
+            m.caption_ids(f2, max_length=LEN)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.caption_ids(f2, max_length=LEN)
+        torch.cuda.synchronize()
+        d2 = (time.perf_counter() - t0) / reps
+        other[f"b{b2}"] = {"value": b2 / d2, "unit": "captions/s", "ms_per_step": d2 * 1e3}
     return {"workload": f"cfg1 CNN-RNN greedy decode, B={Br}, len {LEN}, E={Er}, hidden {Hd}, V={Vr}", "value": Br / dt,
-            "unit": "captions/s", "ms_per_step": dt * 1e3,
+            "unit": "captions/s", "ms_per_step": dt * 1e3, "other_batch_sizes": other,
             "cpu": {"value": Br / cpu_dt, "unit": "captions/s", "ms_per_step": cpu_dt * 1e3,
                     "cores": torch.get_num_threads(), "kind": "port",
                     "sample": f"{n} batches of {Br} in 3 s, oracle restatement of the reference loop"}}
