@@ -9,7 +9,7 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libcapdec.so")
 LIB_TUNE = os.path.join(HERE, "libcapdec_tune.so")
-SOURCES = ["gemm.hip", "ops.hip", "lstm.hip", "engine.hip", "train_ops.hip"]
+SOURCES = ["gemm.hip", "ops.hip", "lstm.hip", "engine.hip", "train_ops.hip", "decode_fused.hip"]
 
 
 def _hipcc():

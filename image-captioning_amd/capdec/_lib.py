@@ -19,6 +19,7 @@ GEMM_ATOMIC = 8
 GEMM_SPLITK = 16
 DECODE_NO_S1_SHORTCUT = 1
 DECODE_FOLD_MEMORY = 2
+DECODE_NO_FUSED_LAYERS = 4
 VOCAB_STATIC_MAX_ELEMS = 1 << 20
 E2BIG = -7
 

@@ -4,6 +4,7 @@ owns the workspace tensor, and resolves rows that generated <PAD> through the ex
 The decode loops themselves live in libcapdec.so (csrc/engine.hip); one C call enqueues every step.
 """
 import ctypes
+import warnings
 
 import torch
 
@@ -91,10 +92,12 @@ class VocabProbe:
 
 
 def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=False, resolve_dirty=True, probe=None,
-                  to_cpu=True, extra_cap=0, fold_memory=False):
+                  to_cpu=True, extra_cap=0, fold_memory=False, fused_layers=True, keep_workspace=None):
     """Greedy decode on the GPU.  enc [B,S,E] fp32.  Returns (ids int64 [B,max_length] padded with -1, lengths
     int32 [B], number of rows that went through the exact path).  ids/lengths are CPU tensors unless
-    ``to_cpu=False`` (then they stay on the device, e.g. for a cross-rank gather)."""
+    ``to_cpu=False`` (then they stay on the device, e.g. for a cross-rank gather).  ``fused_layers=False`` keeps the
+    launch-per-operation form of a step where the library would run all decoder layers as one launch (capdec.h,
+    CAPDEC_DECODE_NO_FUSED_LAYERS).  ``keep_workspace``: a list that receives the workspace tensor (tests)."""
     lib = _lib.load()
     if not enc.is_cuda or enc.dtype != torch.float32:
         raise RuntimeError("capdec: enc must be an fp32 tensor on the GPU (HIP); there is no CPU path")
@@ -132,6 +135,10 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
                 # no_s1_shortcut: the general cross-attention kernels whatever the number of memory rows;
                 # fold_memory: the folded form (taken by itself for long memories) forced for any S >= 3
                 flags = (_lib.DECODE_NO_S1_SHORTCUT if no_s1_shortcut else 0) | (_lib.DECODE_FOLD_MEMORY if fold_memory else 0)
+                if not fused_layers:
+                    flags |= _lib.DECODE_NO_FUSED_LAYERS
+                if keep_workspace is not None:
+                    keep_workspace.append(ws)
                 _lib.check(lib.capdec_tf_greedy_decode(ctypes.byref(ref.c), enc.data_ptr(), B, S, max_length, sos, eos,
                                                        flags, extra_cap, ws.data_ptr(), ws.numel(), out_ids.data_ptr(),
                                                        out_len.data_ptr(), dirty.data_ptr(),
@@ -144,7 +151,11 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
                         rows = torch.nonzero(host[2], as_tuple=False).flatten()
                     else:
                         rows = torch.nonzero(dirty.cpu(), as_tuple=False).flatten()
+                        host = (None, None, dirty.cpu())
                     n_dirty = int(rows.numel())
+                    if n_dirty and bool((host[2] == 2).any()):
+                        warnings.warn("capdec: a workgroup of the one-launch decoder layers gave up waiting for its team; "
+                                      "the batch is re-decoded on the exact path", RuntimeWarning)
                     if n_dirty:
                         # samples whose <PAD>-induced re-run rows did not fit the step's row list (see capdec.h):
                         # redo those samples on the exact full-prefix path

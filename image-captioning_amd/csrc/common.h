@@ -99,6 +99,38 @@ inline bool capdec_attention_memory_supported(int E) { return E == 64 || E == 12
 int capdec_launch_attention_memory_rows(const float* qp, int64_t ldq, const float* mem, int S, int E, int H, float scale,
                                         float* ctx, int64_t ldc, int Rcap, const int32_t* row_map, int map_div,
                                         const int32_t* rows_dev, hipStream_t s);
+// ---- all decoder layers of a cached decode step in one launch (decode_fused.hip) ---------------------------------------
+// Rows are cut into blocks of CAPDEC_FUSED_ROWS, each walked through the layers by a team of CAPDEC_FUSED_TEAM workgroups.
+#define CAPDEC_FUSED_TEAM 8
+#define CAPDEC_FUSED_ROWS 32
+#define CAPDEC_FUSED_MAX_LAYERS 8
+struct capdec_fused_layer {
+    const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *w1, *b1, *w2, *b2;
+    const float *n1g, *n1b, *n2g, *n2b, *n3g, *n3b;
+    const float* cc;          // [B][E] the cross-attention block of a single memory row, per sample
+    float *kc, *vc;           // [B][max_len][E] self-attention cache of this layer
+};
+struct capdec_fused_args {
+    capdec_fused_layer ly[CAPDEC_FUSED_MAX_LAYERS];
+    int L, B, max_len, Tk;    // Tk = keys of this step (step index + 1)
+    int extra_teams;          // teams at the front of the grid for the re-run rows (slab rows B, B+1, ...)
+    int main_teams;           // ceil(B / CAPDEC_FUSED_ROWS)
+    int cache_bytes;          // B * max_len * E * 4
+    float* x;                 // [B + extra rows][E] row-major: the step's input rows; receives the last LayerNorm's rows
+    float* q;                 // [teams][32][E] row-major queries
+    float *f_ctx, *f_y, *f_h, *f_z;   // [teams][E/4][32][4] fragment-major exchange buffers
+    const int32_t* tok; int64_t ldtok;
+    const int32_t* rowmap;    // [B + extra rows] sample * max_len + position
+    const int32_t* nrows;     // device scalar: B + re-run rows of this step, 0 once every caption has finished
+    const int32_t* infected;  // [B] 1: the sample's rows are all in the re-run list (its main row stores nothing)
+    unsigned* ctr;            // [teams + 1][32] arrival counters of this step (one per 128-byte line), zero before the launch
+    unsigned* err;            // raised by a workgroup whose bounded wait ran out
+    unsigned long long* trace;   // probe builds only (CAPDEC_FUSED_TRACE): [8][64] stage timestamps of team trace_team
+    int trace_team;
+};
+bool capdec_fused_layers_supported(int E, int H, int L, int64_t B, int max_len);
+int capdec_launch_fused_layers(const capdec_fused_args& a, int E, hipStream_t s);
+
 int capdec_launch_attention_rows(const float* q, int64_t ldq, const float* k, int64_t ldk, int64_t sk, const float* v,
                                  int64_t ldv, int64_t sv, float* out, int64_t ldo, int Rcap, int H, int Tk, int dk,
                                  int causal, const int32_t* ids, int64_t ldid, const int32_t* row_map, int map_div,

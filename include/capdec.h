@@ -472,6 +472,11 @@ int capdec_event_elapsed_ms(void* begin, void* end, float* ms);
 #define CAPDEC_DECODE_NO_S1_SHORTCUT 1   /* run the general cross-attention kernels even when S == 1 or S == 2 (the
                                             closed forms: one key -> the block is a per-sample constant; two keys ->
                                             a per-sample constant plus one logistic gate per head) */
+#define CAPDEC_DECODE_NO_FUSED_LAYERS 4   /* S == 1, E == 512, H == 4, L <= 8, max_len <= 64: a step's decoder layers run as
+                                            ONE launch (teams of 8 workgroups walk blocks of 32 rows through the whole
+                                            chain, csrc/decode_fused.hip); this flag keeps the launch-per-operation form.
+                                            A workgroup of that launch whose bounded wait for its team runs out sets
+                                            out_dirty to 2 for every sample: redo them with capdec_tf_greedy_decode_exact */
 int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, int S, int max_len, int sos, int eos,
                             int flags, int extra_cap, void* workspace, size_t workspace_bytes, int64_t* out_ids,
                             int32_t* out_len, int32_t* out_dirty, const capdec_probe* probe /*nullable*/, void* stream);
