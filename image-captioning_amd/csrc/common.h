@@ -100,10 +100,12 @@ int capdec_launch_attention_memory_rows(const float* qp, int64_t ldq, const floa
                                         float* ctx, int64_t ldc, int Rcap, const int32_t* row_map, int map_div,
                                         const int32_t* rows_dev, hipStream_t s);
 // ---- all decoder layers of a cached decode step in one launch (decode_fused.hip) ---------------------------------------
-// Rows are cut into blocks of CAPDEC_FUSED_ROWS, each walked through the layers by a team of CAPDEC_FUSED_TEAM workgroups.
+// Rows are cut into blocks of CAPDEC_FUSED_ROWS, each walked through the layers by a team of CAPDEC_FUSED_TEAM workgroups;
+// a team carries up to CAPDEC_FUSED_SIDE_ROWS earlier <PAD> positions of its samples along (two layers only).
 #define CAPDEC_FUSED_TEAM 8
 #define CAPDEC_FUSED_ROWS 32
-#define CAPDEC_FUSED_MAX_LAYERS 8
+#define CAPDEC_FUSED_SIDE_ROWS 16
+#define CAPDEC_FUSED_MAX_LAYERS 2
 struct capdec_fused_layer {
     const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *w1, *b1, *w2, *b2;
     const float *n1g, *n1b, *n2g, *n2b, *n3g, *n3b;
@@ -113,17 +115,19 @@ struct capdec_fused_layer {
 struct capdec_fused_args {
     capdec_fused_layer ly[CAPDEC_FUSED_MAX_LAYERS];
     int L, B, max_len, Tk;    // Tk = keys of this step (step index + 1)
-    int extra_teams;          // teams at the front of the grid for the re-run rows (slab rows B, B+1, ...)
-    int main_teams;           // ceil(B / CAPDEC_FUSED_ROWS)
+    int teams;                // ceil(B / CAPDEC_FUSED_ROWS)
     int cache_bytes;          // B * max_len * E * 4
-    float* x;                 // [B + extra rows][E] row-major: the step's input rows; receives the last LayerNorm's rows
+    float* x;                 // [B][E] row-major: the step's input rows; receives the last LayerNorm's rows
     float* q;                 // [teams][32][E] row-major queries
     float *f_ctx, *f_y, *f_h, *f_z;   // [teams][E/4][32][4] fragment-major exchange buffers
+    float *s_ctx, *s_y, *s_h, *s_z;   // [teams][E/4][16][4] the same of the side rows
     const int32_t* tok; int64_t ldtok;
-    const int32_t* rowmap;    // [B + extra rows] sample * max_len + position
-    const int32_t* nrows;     // device scalar: B + re-run rows of this step, 0 once every caption has finished
-    const int32_t* infected;  // [B] 1: the sample's rows are all in the re-run list (its main row stores nothing)
-    unsigned* ctr;            // [teams + 1][32] arrival counters of this step (one per 128-byte line), zero before the launch
+    const int32_t* nrows;     // device scalar: 0 once every caption has finished
+    const int32_t* done;      // [B]
+    const int32_t* pcount;    // [teams] <PAD> positions recorded for the team's samples (beyond 16: flagged for the exact path)
+    const int32_t* plist;     // [teams][16] sample * max_len + position
+    const float *emb, *pe;
+    unsigned* ctr;            // [teams][32] arrival counters of this step (one per 128-byte line), zero before the launch
     unsigned* err;            // raised by a workgroup whose bounded wait ran out
     unsigned long long* trace;   // probe builds only (CAPDEC_FUSED_TRACE): [8][64] stage timestamps of team trace_team
     int trace_team;

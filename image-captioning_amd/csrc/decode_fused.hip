@@ -1,6 +1,6 @@
 // All decoder layers of one KV-cached greedy decode step in ONE launch (transformer.py:83-90 run once per step of
 // the loop at transformer.py:151-171), for the single-memory-row form of the cross-attention block (S == 1: the block
-// is one vector per sample and layer, see capdec_tf_greedy_decode).
+// is one vector per sample and layer, see capdec_tf_greedy_decode) and at most two layers.
 //
 // A decode step is a chain of small dependent operations per row: q/k/v projections -> self-attention over the row's
 // own cache -> output projection + residual -> LayerNorm 1, + cross-attention constant, LayerNorm 2 -> fc1 + ReLU ->
@@ -21,13 +21,20 @@
 //   - LayerNorm runs on the fragments in registers (row sums over the 8 k-slabs meet in LDS), redundantly in the 8
 //     members, so it costs no hand-off of its own;
 //   - attention: a member takes one head for 16 of the 32 rows (two (row, head) pairs per wavefront).
-// Rows that re-run earlier positions of a sample that generated <PAD> (see capdec_tf_greedy_decode) form teams of their
-// own at the FRONT of the grid; such a sample's rows attend to cache rows that other re-run rows rewrite in the same
-// step, so those teams meet on one more counter between the projections and the attention of every layer.  They hold
-// every row of such a sample, its newest position included (the main team's copy of that row stores nothing).
-// Progress: a team only ever waits for its own members (the re-run teams: for one another); workgroups are dispatched
-// in index order, so the members of the oldest unfinished team are resident or next in line.  Every wait is a bounded
-// spin: a workgroup that gives up raises `err` and returns, and the caller re-decodes the batch on the exact path.
+//
+// Generated <PAD> tokens.  The reference masks a <PAD> QUERY row, which then attends uniformly over the CURRENT length
+// (transformer.py:117-123), so the layer-0 output of such a position changes at every later step.  Layer-0 keys and
+// values depend on the embeddings only and the causal rows around it never see the difference in layer 0; what
+// changes is the <PAD> position's INPUT TO LAYER 1, i.e. its layer-1 key and value, which the sample's newest row
+// attends to.  (Later rows' layer-1 outputs change too, but with two layers nothing reads them.)  So a team carries
+// the <PAD> positions of its own samples along as up to 16 SIDE rows (a 16-row MFMA tile next to the 32-row one, on
+// the same weight slabs): mean of the layer-0 values -> output projection -> LayerNorms -> FFN -> LayerNorm 3 ->
+// layer-1 key and value, written to the cache before the team's layer-1 attention reads them.  With one layer nothing
+// has to be re-run at all.  A team whose samples hold more than 16 <PAD> positions flags the surplus samples for the
+// exact path (out_dirty).
+// Progress: a team only ever waits for its own members; workgroups are dispatched in index order, so the members of the
+// oldest unfinished team are resident or next in line.  Every wait is a bounded spin: a workgroup that gives up raises
+// `err` and returns, and the caller re-decodes the batch on the exact path.
 #include "common.h"
 #include <limits.h>
 #include <math.h>
@@ -39,6 +46,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FT_TEAM = CAPDEC_FUSED_TEAM;
 constexpr int FT_ROWS = CAPDEC_FUSED_ROWS;
+constexpr int FT_SIDE = CAPDEC_FUSED_SIDE_ROWS;
 constexpr int FT_WAVES = 8;
 constexpr int FT_THREADS = 512;
 constexpr unsigned FT_SPIN_LIMIT = 1u << 20;
@@ -50,7 +58,9 @@ struct FT {
     static constexpr int KW = E / FT_WAVES;           // contraction range of a wavefront
     static constexpr int NH = KW / 32;                // 32-deep half-slabs per wavefront and projection
     static constexpr int NT = NC / 32;                // 32x32 accumulators per wavefront
-    static constexpr int NA = KW / 8;                 // 16-byte activation fragments per lane
+    static constexpr int NA = KW / 8;                 // 16-byte activation fragments per lane (32-row tile)
+    static constexpr int NS = KW / 16;                // the same of the 16-row side tile
+    static constexpr int NCT = NC / 16;               // 16x16 accumulators per wavefront (side tile)
     static constexpr int PIECES = NC / 8;             // global_load_lds instructions per half-slab (8 rows x 128 B each)
     static constexpr int WSLAB = NC * 32;             // floats of one wavefront's half-slab [NC][32]
     static constexpr int WSLOT = FT_WAVES * WSLAB;
@@ -58,14 +68,14 @@ struct FT {
     static constexpr int CST_LD = DK + 4;
     static constexpr int OFF_W0 = 0;
     static constexpr int OFF_W1 = WSLOT;              // second ring slot; the k-split partial tiles between operations
-    static constexpr int OFF_R1 = 2 * WSLOT;          // [NC/4][32][4] own columns of the layer input (residual)
-    static constexpr int OFF_R2 = OFF_R1 + 32 * NC;   // the same of LayerNorm 2's output
-    static constexpr int OFF_CST = OFF_R2 + 32 * NC;  // [16][DK+4] attention outputs before they are stored
+    static constexpr int OFF_R = 2 * WSLOT;           // [NC/4][32][4] own columns of the residual operand (main rows)
+    static constexpr int OFF_RS = OFF_R + 32 * NC;    // [NC/4][16][4] the same of the side rows
+    static constexpr int OFF_CST = OFF_RS + 16 * NC;  // [16][DK+4] attention outputs before they are stored
     static constexpr int OFF_PART = OFF_CST + 16 * CST_LD;      // [2][8][32] LayerNorm partial sums
     static constexpr int OFF_SC = OFF_PART + 2 * FT_WAVES * 32; // [8][64] score rows
-    static constexpr int OFF_META = OFF_SC + FT_WAVES * 64;     // ints: 6 x [32] row descriptors, wait flag
-    static constexpr int LDS_FLOATS = OFF_META + 6 * 32 + 16;
-    static_assert(NH == 2 && NT >= 1 && KW == NC, "team kernel built for E = 512");
+    static constexpr int OFF_META = OFF_SC + FT_WAVES * 64;     // ints: row descriptors, wait flag
+    static constexpr int LDS_FLOATS = OFF_META + 2 * 32 + 4 * 16 + 16;
+    static_assert(NH == 2 && NT >= 1 && KW == NC && NC == 64, "team kernel built for E = 512");
 };
 
 __device__ __forceinline__ int acc_row32(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
@@ -78,26 +88,36 @@ __device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t rs, unsigned by
 }
 
 // one half-slab of a weight slice, straight into this wavefront's part of a ring slot: LDS image [NC][32] floats with
-// the 16-byte slots of a row XOR-swizzled by (row >> 1) & 7 (conflict-free 16-byte fragment reads of 32 rows)
+// the 16-byte slots of a row XOR-swizzled by (row >> 1) & 7 (conflict-free 16-byte fragment reads of 16 or 32 rows).
+// Piece p (8 rows of 128 bytes) of the image comes from rows p*8 + lane/8; the swizzle of a lane's slot depends on p
+// through p & 1 only, so two per-lane offsets serve all pieces and everything else is wavefront-uniform.
+struct LaneOff { int even, odd; };
 template <int E>
-__device__ __forceinline__ void issue_half(const float* __restrict__ W, int member, int wave, int lane, int half,
+__device__ __forceinline__ LaneOff lane_offsets(int lane) {
+    const int r8 = lane >> 3, c = lane & 7;
+    LaneOff o;
+    o.even = (r8 * E + ((c ^ ((r8 >> 1) & 7)) << 2)) * 4;
+    o.odd = (r8 * E + ((c ^ ((4 + (r8 >> 1)) & 7)) << 2)) * 4;
+    return o;
+}
+template <int E>
+__device__ __forceinline__ void issue_half(const float* __restrict__ W, int member, int wave, LaneOff lo, int half,
                                            float* slot) {
     using C = FT<E>;
     float* dst = slot + wave * C::WSLAB;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, E * E * 4, 0x00020000);
+    const int base = ((member * C::NC) * E + wave * C::KW + half * 32) * 4;      // uniform
 #pragma unroll
-    for (int p = 0; p < C::PIECES; ++p) {
-        const int row = p * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const float* src = W + (int64_t)(member * C::NC + row) * E + wave * C::KW + half * 32 + chunk * 4;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + p * 256), 16, 0, 0);
-    }
+    for (int p = 0; p < C::PIECES; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + p * 256), 16,
+                                             (p & 1) ? lo.odd : lo.even, base + p * 8 * E * 4, 0, 0);
 }
 
+// 32 rows: lane (r, h) holds a[kc] = X[r][k0 + kc*8 + 4h + {0..3}]; MFMA m of chunk kc sums k in {kc*8+m, kc*8+4+m}
 template <int E>
-__device__ __forceinline__ void mma_half(const float* slot, int wave, int r, int h, const f32x4* a,
-                                         f32x16 (&acc)[FT<E>::NT]) {
+__device__ __forceinline__ void mma_half(const float* slot, int wave, int lane, const f32x4* a, f32x16 (&acc)[FT<E>::NT]) {
     using C = FT<E>;
+    const int r = lane & 31, h = lane >> 5;
     const float* img = slot + wave * C::WSLAB;
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
@@ -114,35 +134,66 @@ __device__ __forceinline__ void mma_half(const float* slot, int wave, int r, int
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][m], b[t][m], acc[t], 0, 0, 0);
     }
 }
+// 16 side rows: lane (c, g) holds as[kq] = X[c][k0 + kq*16 + 4g + {0..3}]; MFMA m of chunk kq sums k in {kq*16 + 4g' + m}
+template <int E>
+__device__ __forceinline__ void mma_half_side(const float* slot, int wave, int lane, const f32x4* as,
+                                              f32x4 (&acc)[FT<E>::NCT]) {
+    using C = FT<E>;
+    const int c = lane & 15, g = lane >> 4;
+    const float* img = slot + wave * C::WSLAB;
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+#pragma unroll
+        for (int ct = 0; ct < C::NCT; ++ct) {
+            const int row = ct * 16 + c;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(img + row * 32 + ((((kq * 4 + g) ^ ((row >> 1) & 7))) << 2));
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[kq][m], b[m], acc[ct], 0, 0, 0);
+        }
+    }
+}
 
-// NPROJ projections of the same activation fragments.  The stream of half-slabs W[0] half 0, W[0] half 1, W[1] half 0,
-// ... alternates between the two ring slots; its first two entries were issued before the call, entry n + 2 is issued
-// as soon as this wavefront has read entry n, and once slot 0 is free for good the first half-slab of `next` (the next
+// NPROJ projections streamed through the ring.  The stream of half-slabs W[0] half 0, W[0] half 1, W[1] half 0, ...
+// alternates between the two ring slots; its first two entries were issued before the call, entry n + 2 is issued as
+// soon as this wavefront has read entry n, and once slot 0 is free for good the first half-slab of `next` (the next
 // operation's weights; nullable) follows.  Nothing else of this wavefront is in flight inside the loop, so the counted
-// waits see exactly the ring's loads (they retire in order).
-template <int E, int NPROJ>
+// waits see exactly the ring's loads (they retire in order).  Projection p multiplies the 32-row tile when bit p of
+// MAIN_MASK is set (accumulators acc[0], acc[1], ... in projection order) and the 16-row side tile when bit p of
+// SIDE_MASK is set and `side` holds (uniform over the workgroup; accumulators accs[0], ...).
+constexpr int popcount_c(int m) { return m ? (m & 1) + popcount_c(m >> 1) : 0; }
+constexpr int atleast1(int n) { return n < 1 ? 1 : n; }
+template <int E, int NPROJ, int MAIN_MASK, int SIDE_MASK>
 __device__ __forceinline__ void gemm_stream(float* lds, const float* const (&W)[NPROJ], const float* next, int member,
-                                            int wave, int lane, const f32x4 (&a)[FT<E>::NA],
-                                            f32x16 (&acc)[NPROJ][FT<E>::NT]) {
+                                            int wave, int lane, LaneOff lo, const f32x4 (&a)[FT<E>::NA],
+                                            f32x16 (&acc)[atleast1(popcount_c(MAIN_MASK))][FT<E>::NT], bool side,
+                                            const f32x4 (&as)[FT<E>::NS],
+                                            f32x4 (&accs)[atleast1(popcount_c(SIDE_MASK))][FT<E>::NCT]) {
     using C = FT<E>;
     constexpr int N = NPROJ * C::NH;
-    const int r = lane & 31, h = lane >> 5;
     float* slot0 = lds + C::OFF_W0;
     float* slot1 = lds + C::OFF_W1;
 #pragma unroll
-    for (int p = 0; p < NPROJ; ++p)
+    for (int p = 0; p < popcount_c(MAIN_MASK); ++p)
 #pragma unroll
         for (int t = 0; t < C::NT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[p][t][e] = 0.f;
 #pragma unroll
+    for (int p = 0; p < popcount_c(SIDE_MASK); ++p)
+#pragma unroll
+        for (int t = 0; t < C::NCT; ++t) accs[p][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
     for (int n = 0; n < N; ++n) {
         if (n == 0 || (n == N - 1 && !next)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PIECES) : "memory");
-        mma_half<E>((n & 1) ? slot1 : slot0, wave, r, h, &a[(n % C::NH) * 4], acc[n / C::NH]);
+        const int p = n / C::NH, hf = n % C::NH;
+        const float* slot = (n & 1) ? slot1 : slot0;
+        if ((MAIN_MASK >> p) & 1) mma_half<E>(slot, wave, lane, &a[hf * 4], acc[popcount_c(MAIN_MASK & ((1 << p) - 1))]);
+        if (((SIDE_MASK >> p) & 1) && side)
+            mma_half_side<E>(slot, wave, lane, &as[hf * 2], accs[popcount_c(SIDE_MASK & ((1 << p) - 1))]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wavefront's fragment reads of the slot are done
-        if (n + 2 < N) issue_half<E>(W[(n + 2) / C::NH], member, wave, lane, (n + 2) % C::NH, (n & 1) ? slot1 : slot0);
-        else if (n + 2 == N && next) issue_half<E>(next, member, wave, lane, 0, slot0);
+        if (n + 2 < N) issue_half<E>(W[(n + 2) / C::NH], member, wave, lo, (n + 2) % C::NH, (n & 1) ? slot1 : slot0);
+        else if (n + 2 == N && next) issue_half<E>(next, member, wave, lo, 0, slot0);
     }
 }
 
@@ -161,6 +212,20 @@ __device__ __forceinline__ void write_partial(float* lds, int wave, int lane, co
             d[i * C::NC + ((((j >> 2) ^ (i & 15)) << 2) | (j & 3))] = acc[t][e];
         }
 }
+// the 16 x NC partial tile of the side rows: register e of lane (c, g) is row 4g + e, column ct*16 + c
+template <int E>
+__device__ __forceinline__ void write_partial_side(float* lds, int wave, int lane, const f32x4 (&acc)[FT<E>::NCT]) {
+    using C = FT<E>;
+    const int c = lane & 15, g = lane >> 4;
+    float* d = lds + C::OFF_W1 + wave * C::WSLAB;
+#pragma unroll
+    for (int ct = 0; ct < C::NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g + e, j = ct * 16 + c;
+            d[i * C::NC + ((((j >> 2) ^ (i & 15)) << 2) | (j & 3))] = acc[ct][e];
+        }
+}
 template <int E>
 __device__ __forceinline__ f32x4 sum_partials(const float* lds, int i, int sl) {
     using C = FT<E>;
@@ -172,13 +237,10 @@ __device__ __forceinline__ f32x4 sum_partials(const float* lds, int i, int sl) {
 }
 
 // Every storing wavefront drains its stores, the workgroup meets, one lane publishes.
-__device__ __forceinline__ void team_signal(unsigned* c0, unsigned* c1) {
+__device__ __forceinline__ void team_signal(unsigned* ctr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(c0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c1) __hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // One lane polls (relaxed, L1-bypassing), the workgroup meets behind it; false (for every thread) when the spin ran out.
 __device__ __forceinline__ bool team_wait(unsigned* ctr, unsigned target, unsigned* err, int* flag) {
@@ -201,56 +263,65 @@ __device__ __forceinline__ bool team_wait(unsigned* ctr, unsigned target, unsign
     return ok;
 }
 
-template <int E>
-__device__ __forceinline__ void load_frags(__amdgpu_buffer_rsrc_t rs, int wave, int lane, f32x4 (&a)[FT<E>::NA]) {
+// Fragments of a [k/4][ROWS][4] exchange block: lane (row, g) of wavefront w loads the 16-byte slots w*KW/4 + kf*G + g
+template <int E, int NF, int RB>
+__device__ __forceinline__ void load_frags(__amdgpu_buffer_rsrc_t rs, int wave, int lane, f32x4 (&a)[NF]) {
     using C = FT<E>;
-    const int r = lane & 31, h = lane >> 5;
+    constexpr int ROWS = 1 << RB, G = 64 >> RB;
+    const int row = lane & (ROWS - 1), g = lane >> RB;
 #pragma unroll
-    for (int kc = 0; kc < C::NA; ++kc) a[kc] = load_sc1(rs, (unsigned)(((wave * (C::KW / 4) + kc * 2 + h) * 32 + r) * 16));
+    for (int kf = 0; kf < NF; ++kf) a[kf] = load_sc1(rs, (unsigned)(((wave * (C::KW / 4) + kf * G + g) * ROWS + row) * 16));
 }
 
-// LayerNorm (eps 1e-5, affine) of the 32 rows held as fragments: lane (r, h) of wavefront w holds the columns
-// w*KW + kc*8 + 4h + {0..3} of row r.  Two-pass mean / variance; the 8 wavefronts' row sums meet in LDS.
-template <int E>
-__device__ __forceinline__ void ln_frags(f32x4 (&a)[FT<E>::NA], const float* __restrict__ gamma,
-                                         const float* __restrict__ beta, float* part, int& pb, int wave, int lane) {
+// LayerNorm (eps 1e-5, affine) of rows held as fragments: lane (row, g) of wavefront w holds the columns
+// w*KW + kf*4G + 4g + {0..3} of its row (32 rows: G = 2; 16 rows: G = 4).  Two-pass mean / variance; the 8 wavefronts'
+// row sums meet in LDS.
+template <int E, int NF, int RB>
+__device__ __forceinline__ void ln_frags(f32x4 (&a)[NF], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* part, int& pb, int wave, int lane) {
     using C = FT<E>;
-    const int r = lane & 31, h = lane >> 5;
+    constexpr int ROWS = 1 << RB, G = 64 >> RB;
+    const int row = lane & (ROWS - 1), g = lane >> RB;
     float s = 0.f;
 #pragma unroll
-    for (int kc = 0; kc < C::NA; ++kc) s += (a[kc][0] + a[kc][1]) + (a[kc][2] + a[kc][3]);
-    s += __shfl_xor(s, 32, 64);
+    for (int kf = 0; kf < NF; ++kf) s += (a[kf][0] + a[kf][1]) + (a[kf][2] + a[kf][3]);
+#pragma unroll
+    for (int o = ROWS; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
     float* p = part + pb * (FT_WAVES * 32);
     pb ^= 1;
-    if (h == 0) p[wave * 32 + r] = s;
+    if (g == 0) p[wave * 32 + row] = s;
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 32 + r];
+    for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 32 + row];
     const float mean = tot / (float)E;
     float q = 0.f;
 #pragma unroll
-    for (int kc = 0; kc < C::NA; ++kc) {
-        a[kc] -= mean;
-        q += (a[kc][0] * a[kc][0] + a[kc][1] * a[kc][1]) + (a[kc][2] * a[kc][2] + a[kc][3] * a[kc][3]);
+    for (int kf = 0; kf < NF; ++kf) {
+        a[kf] -= mean;
+        q += (a[kf][0] * a[kf][0] + a[kf][1] * a[kf][1]) + (a[kf][2] * a[kf][2] + a[kf][3] * a[kf][3]);
     }
-    q += __shfl_xor(q, 32, 64);
+#pragma unroll
+    for (int o = ROWS; o < 64; o <<= 1) q += __shfl_xor(q, o, 64);
     p = part + pb * (FT_WAVES * 32);
     pb ^= 1;
-    if (h == 0) p[wave * 32 + r] = q;
+    if (g == 0) p[wave * 32 + row] = q;
     __syncthreads();
     tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 32 + r];
+    for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 32 + row];
     const float rstd = 1.0f / sqrtf(tot / (float)E + 1e-5f);
-    const int c0 = wave * C::KW + 4 * h;
+    const int c0 = wave * C::KW + 4 * g;
 #pragma unroll
-    for (int kc = 0; kc < C::NA; ++kc) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c0 + kc * 8);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c0 + kc * 8);
-        a[kc] = a[kc] * rstd * g + bb;
+    for (int kf = 0; kf < NF; ++kf) {
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(gamma + c0 + kf * 4 * G);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c0 + kf * 4 * G);
+        a[kf] = a[kf] * rstd * gg + bb;
     }
 }
+
+// buffer descriptor of `bytes` bytes at p, made where it is used (four scalar registers; none stay live across stages)
+#define FT_RS(p, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, (bytes), 0x00020000)
 
 // Stage timestamps of one team (100 MHz wall clock), compiled in only for the probe under tools/exp.
 #ifdef CAPDEC_FUSED_TRACE
@@ -271,98 +342,95 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int sc_ = lane & 15, sg_ = lane >> 4;             // side tile: lane = (row, k group)
     // consecutive workgroup ids go round-robin to the XCDs: the members of a team share id & 7 (speed only)
     const int xg = blockIdx.x & 7, gslot = blockIdx.x >> 3;
     const int team = (gslot >> 3) * 8 + xg, member = gslot & 7;
-    const int nteams = A.extra_teams + A.main_teams;
-    if (team >= nteams) return;
-    const int nrows = A.nrows[0];
-    if (nrows <= 0) return;                                 // every caption has finished
-    const bool extra = team < A.extra_teams;
-    const int n_act_extra = (max(nrows - A.B, 0) + FT_ROWS - 1) / FT_ROWS;
-    if (extra && team >= n_act_extra) return;
+    if (team >= A.teams) return;
+    if (A.nrows[0] <= 0) return;                            // every caption has finished
 
     float* slot0 = lds + C::OFF_W0;
     float* slot1 = lds + C::OFF_W1;
-    issue_half<E>(A.ly[0].wq, member, wave, lane, 0, slot0);
-    issue_half<E>(A.ly[0].wq, member, wave, lane, 1, slot1);
+    const LaneOff lo = lane_offsets<E>(lane);
+    issue_half<E>(A.ly[0].wq, member, wave, lo, 0, slot0);
+    issue_half<E>(A.ly[0].wq, member, wave, lo, 1, slot1);
 
     int* meta = reinterpret_cast<int*>(lds + C::OFF_META);
-    int *s_map = meta, *s_b = meta + 32, *s_pos = meta + 64, *s_flags = meta + 96, *s_xrow = meta + 128, *s_src = meta + 160;
-    int* s_ok = meta + 192;
+    int *s_b = meta, *s_flags = meta + 32;                  // main rows: sample (clamped), bit 0 live, bit 1 <PAD> query
+    int *ss_map = meta + 64, *ss_b = meta + 80, *ss_pos = meta + 96, *ss_act = meta + 112;   // side rows
+    int* s_ok = meta + 128;
+    const int pos_new = A.Tk - 1;
     if (tid < FT_ROWS) {
-        int srow, store, xrow;
-        if (extra) {
-            srow = A.B + team * FT_ROWS + tid;
-            const bool act = srow < nrows;
-            if (!act) srow = 0;
-            const int m = A.rowmap[srow];
-            const int b = m / A.max_len, pos = m - b * A.max_len;
-            store = act;
-            xrow = (act && pos == A.Tk - 1) ? b : -1;        // the sample's newest position feeds the vocabulary projection
-            s_map[tid] = m; s_b[tid] = b; s_pos[tid] = pos;
-        } else {
-            srow = (team - A.extra_teams) * FT_ROWS + tid;
-            const bool act = srow < A.B;
-            if (!act) srow = 0;
-            const int m = A.rowmap[srow];
-            const int b = m / A.max_len, pos = m - b * A.max_len;
-            store = act && !A.infected[b];                   // a sample with re-run rows is computed by their teams
-            xrow = store ? srow : -1;
-            s_map[tid] = m; s_b[tid] = b; s_pos[tid] = pos;
-        }
-        const int pad = A.tok[(int64_t)s_b[tid] * A.ldtok + s_pos[tid]] == 0;
-        s_flags[tid] = store | (pad << 1);
-        s_xrow[tid] = xrow;
-        s_src[tid] = srow;
+        const int b0 = team * FT_ROWS + tid;
+        const bool act = b0 < A.B;
+        const int b = act ? b0 : team * FT_ROWS;
+        const int pad = A.tok[(int64_t)b * A.ldtok + pos_new] == 0;
+        s_b[tid] = b;
+        s_flags[tid] = (act ? 1 : 0) | (pad << 1);
+    } else if (tid < FT_ROWS + FT_SIDE) {
+        // <PAD> positions of the team's samples before the newest one, still decoding
+        const int sr = tid - FT_ROWS;
+        const int n = A.L >= 2 ? min(A.pcount[team], FT_SIDE) : 0;
+        const int m = sr < n ? A.plist[team * FT_SIDE + sr] : team * FT_ROWS * A.max_len;
+        const int b = m / A.max_len, pos = m - b * A.max_len;
+        ss_map[sr] = m;
+        ss_b[sr] = b;
+        ss_pos[sr] = pos;
+        ss_act[sr] = (sr < n && pos < pos_new && !A.done[b]) ? 1 : 0;
     }
     __syncthreads();
+    bool side = false;
+#pragma unroll
+    for (int i = 0; i < FT_SIDE; ++i) side |= ss_act[i] != 0;
 
     unsigned* tctr = A.ctr + (size_t)team * 32;
-    unsigned* sctr = extra ? A.ctr + (size_t)nteams * 32 : nullptr;
     unsigned nsig = 0;
-    const size_t tb = (size_t)team * FT_ROWS * E;            // this team's 32 x E block in every exchange buffer
-    const int blk_bytes = FT_ROWS * E * 4;
-    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(A.q + tb, 0, blk_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_ctx = __builtin_amdgcn_make_buffer_rsrc(A.f_ctx + tb, 0, blk_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(A.f_y + tb, 0, blk_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(A.f_h + tb, 0, blk_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(A.f_z + tb, 0, blk_bytes, 0x00020000);
+    const size_t tb = (size_t)team * FT_ROWS * E;           // this team's 32 x E block in the exchange buffers
+    const size_t tsb = (size_t)team * FT_SIDE * E;          // and its 16 x E block in the side rows' buffers
+    const int blk = FT_ROWS * E * 4, sblk = FT_SIDE * E * 4;
     float* part = lds + C::OFF_PART;
     int pb = 0;
-    f32x4* R1 = reinterpret_cast<f32x4*>(lds + C::OFF_R1);
-    f32x4* R2 = reinterpret_cast<f32x4*>(lds + C::OFF_R2);
+    f32x4* R = reinterpret_cast<f32x4*>(lds + C::OFF_R);
+    f32x4* RS = reinterpret_cast<f32x4*>(lds + C::OFF_RS);
     // epilogue maps: (ia, sa) for fragment-major stores (rows fastest), (ib, sb) for row-major stores (columns fastest)
     const int ia = tid & 31, sa = tid >> 5, ib = tid >> 4, sb = tid & 15;
     const unsigned frag_off = (unsigned)(((member * (C::NC / 4) + sa) * 32 + ia) * 16);
+    // side rows (the first 256 threads): (ja, ta) rows fastest, (jb, tb_) columns fastest
+    const int ja = tid & 15, ta = (tid >> 4) & 15, jb = (tid >> 4) & 15, tb_ = tid & 15;
+    const unsigned sfrag_off = (unsigned)(((member * (C::NC / 4) + ta) * FT_SIDE + ja) * 16);
+    const bool sthr = tid < 256;
     const int cache_bytes = A.cache_bytes;
 
     f32x4 a[C::NA];
+    f32x4 as[C::NS];                             // (loaded and used only where the team has side rows)
     FT_MARK();                                   // 0: set-up done
     for (int l = 0; l < A.L; ++l) {
         const capdec_fused_layer& ly = A.ly[l];
-        const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(ly.kc, 0, cache_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(ly.vc, 0, cache_bytes, 0x00020000);
+        const bool side_kv = side && l == 1;     // the side rows' layer-1 keys and values
 
         // ---- q, k, v projections of the layer input ---------------------------------------------------------
         if (l == 0) {
-            const float* xr = A.x + (int64_t)s_src[r] * E + wave * C::KW + 4 * h;
+            const float* xr = A.x + (int64_t)s_b[r] * E + wave * C::KW + 4 * h;
 #pragma unroll
             for (int kc = 0; kc < C::NA; ++kc) a[kc] = *reinterpret_cast<const f32x4*>(xr + kc * 8);
         } else {
             if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
-            load_frags<E>(rs_z, wave, lane, a);
-            ln_frags<E>(a, A.ly[l - 1].n3g, A.ly[l - 1].n3b, part, pb, wave, lane);
+            load_frags<E, C::NA, 5>(FT_RS(A.f_z + tb, blk), wave, lane, a);
+            if (side_kv) load_frags<E, C::NS, 4>(FT_RS(A.s_z + tsb, sblk), wave, lane, as);
+            ln_frags<E, C::NA, 5>(a, A.ly[l - 1].n3g, A.ly[l - 1].n3b, part, pb, wave, lane);
+            if (side_kv) ln_frags<E, C::NS, 4>(as, A.ly[l - 1].n3g, A.ly[l - 1].n3b, part, pb, wave, lane);
         }
         if (wave == member) {
 #pragma unroll
-            for (int kc = 0; kc < C::NA; ++kc) R1[(kc * 2 + h) * 32 + r] = a[kc];
+            for (int kc = 0; kc < C::NA; ++kc) R[(kc * 2 + h) * 32 + r] = a[kc];
         }
         FT_MARK();                               // layer input in registers
         {
             f32x16 acc[3][C::NT];
+            f32x4 accs0[1][C::NCT];
             const float* const W3[3] = {ly.wq, ly.wk, ly.wv};
-            gemm_stream<E, 3>(lds, W3, ly.wo, member, wave, lane, a, acc);
+            // (with side rows the ring goes on with W_k, W_v for them before the next operation's weights)
+            gemm_stream<E, 3, 7, 0>(lds, W3, side_kv ? ly.wk : ly.wo, member, wave, lane, lo, a, acc, false, as, accs0);
             FT_MARK();                           // q, k, v contractions done
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
@@ -371,20 +439,40 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
                 const float* bias = p == 0 ? ly.bq : (p == 1 ? ly.bk : ly.bv);
                 const int col = member * C::NC + sb * 4;
                 const f32x4 v = sum_partials<E>(lds, ib, sb) + *reinterpret_cast<const f32x4*>(bias + col);
-                if (p == 0) store_sc1(rs_q, (unsigned)((ib * E + col) * 4), v);
-                else if (s_flags[ib] & 1) store_sc1(p == 1 ? rs_k : rs_v, ((unsigned)s_map[ib] * (unsigned)E + col) * 4u, v);
+                if (p == 0) store_sc1(FT_RS(A.q + tb, blk), (unsigned)((ib * E + col) * 4), v);
+                else if (s_flags[ib] & 1)
+                    store_sc1(FT_RS(p == 1 ? ly.kc : ly.vc, cache_bytes),
+                              ((unsigned)(s_b[ib] * A.max_len + pos_new) * (unsigned)E + col) * 4u, v);
+                __syncthreads();
+            }
+        }
+        if (side_kv) {
+            // the side rows' layer-1 keys and values: the two weight slices once more, for the 16-row tile alone
+            issue_half<E>(ly.wk, member, wave, lo, 1, slot1);
+            f32x16 acc0[1][C::NT];
+            f32x4 accs[2][C::NCT];
+            const float* const W2[2] = {ly.wk, ly.wv};
+            gemm_stream<E, 2, 0, 3>(lds, W2, ly.wo, member, wave, lane, lo, a, acc0, true, as, accs);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                write_partial_side<E>(lds, wave, lane, accs[p]);
+                __syncthreads();
+                if (sthr && ss_act[jb]) {
+                    const int col = member * C::NC + tb_ * 4;
+                    const f32x4 v = sum_partials<E>(lds, jb, tb_) + *reinterpret_cast<const f32x4*>((p == 0 ? ly.bk : ly.bv) + col);
+                    store_sc1(FT_RS(p == 0 ? ly.kc : ly.vc, cache_bytes), ((unsigned)ss_map[jb] * (unsigned)E + col) * 4u, v);
+                }
                 __syncthreads();
             }
         }
         FT_MARK();                               // q, k, v stored
-        team_signal(tctr, sctr);
+        team_signal(tctr);
         ++nsig;
-        issue_half<E>(ly.wo, member, wave, lane, 1, slot1);
+        issue_half<E>(ly.wo, member, wave, lo, 1, slot1);
         FT_MARK();                               // signalled
 
         // ---- self-attention: member = (head, half of the rows), two (row, head) pairs per wavefront -----------
         if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
-        if (extra && !team_wait(sctr, (unsigned)(n_act_extra * FT_TEAM * (l + 1)), A.err, s_ok)) return;
         FT_MARK();                               // team has q, k, v
         {
             constexpr int NM = C::DK / 16, LPV = C::DK / 4, NGRP = 64 / LPV;
@@ -392,19 +480,22 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
             float* sc = lds + C::OFF_SC + wave * 64;
             float* cst = lds + C::OFF_CST;
             const float scale = sqrtf((float)C::DK);
+            const __amdgpu_buffer_rsrc_t rs_q = FT_RS(A.q + tb, blk);
+            const __amdgpu_buffer_rsrc_t rs_k = FT_RS(ly.kc, cache_bytes);
+            const __amdgpu_buffer_rsrc_t rs_v = FT_RS(ly.vc, cache_bytes);
 #pragma unroll 1
             for (int it = 0; it < 2; ++it) {
                 const int li = 2 * wave + it, i = rbase + li;
-                const int b = s_b[i], pos = s_pos[i];
+                const int b = s_b[i];
                 const bool pad_row = (s_flags[i] & 2) != 0;
-                const int nkeys = pad_row ? A.Tk : min(pos + 1, A.Tk);
+                const int nkeys = A.Tk;          // the newest position sees every key, <PAD> query or not
                 const unsigned kb = ((unsigned)(b * A.max_len) * (unsigned)E + (unsigned)(hd * C::DK)) * 4u;
                 float sum = 1.f;
                 if (!pad_row) {
                     const int prt = lane & 3, kl = lane >> 2;
                     f32x4 qreg[NM];
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) qreg[m] = load_sc1(rs_q, (unsigned)((i * E + hd * C::DK + 4 * prt + 16 * m) * 4));
+                    for (int m = 0; m < NM; ++m) qreg[m] = load_sc1(FT_RS(A.q + tb, blk), (unsigned)((i * E + hd * C::DK + 4 * prt + 16 * m) * 4));
                     for (int j0 = 0; j0 < nkeys; j0 += 16) {
                         const int j = j0 + kl;
                         float d = 0.f;
@@ -457,90 +548,157 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
             for (int idx = tid; idx < 16 * LPV; idx += FT_THREADS) {
                 const int i16 = idx & 15, sl = idx >> 4;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(cst + i16 * C::CST_LD + sl * 4);
-                store_sc1(rs_ctx, (unsigned)(((hd * LPV + sl) * 32 + rbase + i16) * 16), v);
+                store_sc1(FT_RS(A.f_ctx + tb, blk), (unsigned)(((hd * LPV + sl) * 32 + rbase + i16) * 16), v);
+            }
+            if (side && l == 0 && sthr) {
+                // a <PAD> query row attends uniformly over all Tk positions: the mean of the layer's values, the newest
+                // (written by this team a moment ago) included; this member's columns of every side row
+                const int col = member * C::NC + tb_ * 4;
+                const unsigned vb = ((unsigned)(ss_b[jb] * A.max_len) * (unsigned)E + col) * 4u;
+                const float p = 1.0f / (float)A.Tk;
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < A.Tk; ++j) o += load_sc1(rs_v, vb + (unsigned)(j * E * 4)) * p;
+                store_sc1(FT_RS(A.s_ctx + tsb, sblk), (unsigned)(((member * (C::NC / 4) + tb_) * FT_SIDE + jb) * 16), o);
             }
         }
         FT_MARK();                               // attention stored
-        team_signal(tctr, nullptr);
+        team_signal(tctr);
         ++nsig;
         FT_MARK();
+        const bool side_l0 = side && l == 0;     // the side rows walk layer 0 behind the attention
 
         // ---- output projection + residual ---------------------------------------------------------------------
         if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
         FT_MARK();                               // team has the attention output
-        load_frags<E>(rs_ctx, wave, lane, a);
+        load_frags<E, C::NA, 5>(FT_RS(A.f_ctx + tb, blk), wave, lane, a);
+        if (side_l0) load_frags<E, C::NS, 4>(FT_RS(A.s_ctx + tsb, sblk), wave, lane, as);
         {
             f32x16 acc[1][C::NT];
+            f32x4 accs[1][C::NCT];
             const float* const W1[1] = {ly.wo};
-            gemm_stream<E, 1>(lds, W1, ly.w1, member, wave, lane, a, acc);
+            gemm_stream<E, 1, 1, 1>(lds, W1, ly.w1, member, wave, lane, lo, a, acc, side_l0, as, accs);
             FT_MARK();                           // output projection contracted
             write_partial<E>(lds, wave, lane, acc[0]);
             __syncthreads();
             const f32x4 v = sum_partials<E>(lds, ia, sa) + *reinterpret_cast<const f32x4*>(ly.bo + member * C::NC + sa * 4) +
-                            R1[sa * 32 + ia];
-            store_sc1(rs_y, frag_off, v);
+                            R[sa * 32 + ia];
+            store_sc1(FT_RS(A.f_y + tb, blk), frag_off, v);
+            if (side_l0) {
+                __syncthreads();
+                write_partial_side<E>(lds, wave, lane, accs[0]);
+                __syncthreads();
+                if (sthr) {
+                    // residual: the side row's own input, embedding + position
+                    const int col = member * C::NC + ta * 4;
+                    const int id = A.tok[(int64_t)ss_b[ja] * A.ldtok + ss_pos[ja]];
+                    const f32x4 xin = *reinterpret_cast<const f32x4*>(A.emb + (int64_t)id * E + col) +
+                                      *reinterpret_cast<const f32x4*>(A.pe + (int64_t)ss_pos[ja] * E + col);
+                    const f32x4 w = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.bo + col) + xin;
+                    store_sc1(FT_RS(A.s_y + tsb, sblk), sfrag_off, w);
+                }
+            }
         }
         FT_MARK();
-        team_signal(tctr, nullptr);
+        team_signal(tctr);
         ++nsig;
-        issue_half<E>(ly.w1, member, wave, lane, 1, slot1);
+        issue_half<E>(ly.w1, member, wave, lo, 1, slot1);
         FT_MARK();
 
         // ---- LayerNorm 1, + the cross-attention block (one vector per sample), LayerNorm 2, fc1 + ReLU ---------
         f32x4 cadd[C::NA];
+        f32x4 cadds[C::NS];
         {
             const float* cr = ly.cc + (int64_t)s_b[r] * E + wave * C::KW + 4 * h;
 #pragma unroll
             for (int kc = 0; kc < C::NA; ++kc) cadd[kc] = *reinterpret_cast<const f32x4*>(cr + kc * 8);
+            if (side_l0) {
+                const float* cs = ly.cc + (int64_t)ss_b[sc_] * E + wave * C::KW + 4 * sg_;
+#pragma unroll
+                for (int kf = 0; kf < C::NS; ++kf) cadds[kf] = *reinterpret_cast<const f32x4*>(cs + kf * 16);
+            }
         }
         if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
         FT_MARK();                               // team has y
-        load_frags<E>(rs_y, wave, lane, a);
-        ln_frags<E>(a, ly.n1g, ly.n1b, part, pb, wave, lane);
+        load_frags<E, C::NA, 5>(FT_RS(A.f_y + tb, blk), wave, lane, a);
+        if (side_l0) load_frags<E, C::NS, 4>(FT_RS(A.s_y + tsb, sblk), wave, lane, as);
+        ln_frags<E, C::NA, 5>(a, ly.n1g, ly.n1b, part, pb, wave, lane);
 #pragma unroll
         for (int kc = 0; kc < C::NA; ++kc) a[kc] += cadd[kc];
-        ln_frags<E>(a, ly.n2g, ly.n2b, part, pb, wave, lane);
+        ln_frags<E, C::NA, 5>(a, ly.n2g, ly.n2b, part, pb, wave, lane);
+        if (side_l0) {
+            ln_frags<E, C::NS, 4>(as, ly.n1g, ly.n1b, part, pb, wave, lane);
+#pragma unroll
+            for (int kf = 0; kf < C::NS; ++kf) as[kf] += cadds[kf];
+            ln_frags<E, C::NS, 4>(as, ly.n2g, ly.n2b, part, pb, wave, lane);
+        }
         if (wave == member) {
 #pragma unroll
-            for (int kc = 0; kc < C::NA; ++kc) R2[(kc * 2 + h) * 32 + r] = a[kc];
+            for (int kc = 0; kc < C::NA; ++kc) R[(kc * 2 + h) * 32 + r] = a[kc];
+            if (side_l0) {
+#pragma unroll
+                for (int kf = 0; kf < C::NS; ++kf) RS[(kf * 4 + sg_) * FT_SIDE + sc_] = as[kf];
+            }
         }
         FT_MARK();                               // both LayerNorms done
         {
             f32x16 acc[1][C::NT];
+            f32x4 accs[1][C::NCT];
             const float* const W1[1] = {ly.w1};
-            gemm_stream<E, 1>(lds, W1, ly.w2, member, wave, lane, a, acc);
+            gemm_stream<E, 1, 1, 1>(lds, W1, ly.w2, member, wave, lane, lo, a, acc, side_l0, as, accs);
             FT_MARK();
             write_partial<E>(lds, wave, lane, acc[0]);
             __syncthreads();
             f32x4 v = sum_partials<E>(lds, ia, sa) + *reinterpret_cast<const f32x4*>(ly.b1 + member * C::NC + sa * 4);
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-            store_sc1(rs_h, frag_off, v);
+            store_sc1(FT_RS(A.f_h + tb, blk), frag_off, v);
+            if (side_l0) {
+                __syncthreads();
+                write_partial_side<E>(lds, wave, lane, accs[0]);
+                __syncthreads();
+                if (sthr) {
+                    f32x4 w = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.b1 + member * C::NC + ta * 4);
+                    w[0] = fmaxf(w[0], 0.f); w[1] = fmaxf(w[1], 0.f); w[2] = fmaxf(w[2], 0.f); w[3] = fmaxf(w[3], 0.f);
+                    store_sc1(FT_RS(A.s_h + tsb, sblk), sfrag_off, w);
+                }
+            }
         }
         FT_MARK();
-        team_signal(tctr, nullptr);
+        team_signal(tctr);
         ++nsig;
-        issue_half<E>(ly.w2, member, wave, lane, 1, slot1);
+        issue_half<E>(ly.w2, member, wave, lo, 1, slot1);
         FT_MARK();
 
         // ---- fc2 + residual -------------------------------------------------------------------------------------
         if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
         FT_MARK();                               // team has h
-        load_frags<E>(rs_h, wave, lane, a);
+        load_frags<E, C::NA, 5>(FT_RS(A.f_h + tb, blk), wave, lane, a);
+        if (side_l0) load_frags<E, C::NS, 4>(FT_RS(A.s_h + tsb, sblk), wave, lane, as);
         {
             const float* nxt = l + 1 < A.L ? A.ly[l + 1].wq : nullptr;
             f32x16 acc[1][C::NT];
+            f32x4 accs[1][C::NCT];
             const float* const W1[1] = {ly.w2};
-            gemm_stream<E, 1>(lds, W1, nxt, member, wave, lane, a, acc);
+            gemm_stream<E, 1, 1, 1>(lds, W1, nxt, member, wave, lane, lo, a, acc, side_l0, as, accs);
             FT_MARK();
             write_partial<E>(lds, wave, lane, acc[0]);
             __syncthreads();
             const f32x4 v = sum_partials<E>(lds, ia, sa) + *reinterpret_cast<const f32x4*>(ly.b2 + member * C::NC + sa * 4) +
-                            R2[sa * 32 + ia];
-            store_sc1(rs_z, frag_off, v);
+                            R[sa * 32 + ia];
+            store_sc1(FT_RS(A.f_z + tb, blk), frag_off, v);
+            if (side_l0) {
+                __syncthreads();
+                write_partial_side<E>(lds, wave, lane, accs[0]);
+                __syncthreads();
+                if (sthr) {
+                    const f32x4 w = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.b2 + member * C::NC + ta * 4) +
+                                    RS[ta * FT_SIDE + ja];
+                    store_sc1(FT_RS(A.s_z + tsb, sblk), sfrag_off, w);
+                }
+            }
             FT_MARK();
-            team_signal(tctr, nullptr);
+            team_signal(tctr);
             ++nsig;
-            if (nxt) issue_half<E>(nxt, member, wave, lane, 1, slot1);
+            if (nxt) issue_half<E>(nxt, member, wave, lo, 1, slot1);
             FT_MARK();
         }
     }
@@ -548,16 +706,13 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
     // ---- LayerNorm 3 of the last layer: the rows that feed the vocabulary projection -------------------------------
     if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
     FT_MARK();                                   // team has the last layer's z
-    load_frags<E>(rs_z, wave, lane, a);
-    ln_frags<E>(a, A.ly[A.L - 1].n3g, A.ly[A.L - 1].n3b, part, pb, wave, lane);
+    load_frags<E, C::NA, 5>(FT_RS(A.f_z + tb, blk), wave, lane, a);
+    ln_frags<E, C::NA, 5>(a, A.ly[A.L - 1].n3g, A.ly[A.L - 1].n3b, part, pb, wave, lane);
     FT_MARK();
-    if (wave == member) {
-        const int xr = s_xrow[r];
-        if (xr >= 0) {
-            float* dst = A.x + (int64_t)xr * E + wave * C::KW + 4 * h;
+    if (wave == member && (s_flags[r] & 1)) {
+        float* dst = A.x + (int64_t)s_b[r] * E + wave * C::KW + 4 * h;
 #pragma unroll
-            for (int kc = 0; kc < C::NA; ++kc) *reinterpret_cast<f32x4*>(dst + kc * 8) = a[kc];
-        }
+        for (int kc = 0; kc < C::NA; ++kc) *reinterpret_cast<f32x4*>(dst + kc * 8) = a[kc];
     }
 }
 
@@ -567,12 +722,12 @@ bool g_attr_done[64] = {};
 }  // namespace
 
 bool capdec_fused_layers_supported(int E, int H, int L, int64_t B, int max_len) {
-    return E == 512 && H == 4 && L >= 1 && L <= CAPDEC_FUSED_MAX_LAYERS && max_len <= 64 &&
+    return E == 512 && H == 4 && L >= 1 && L <= 2 && max_len <= 64 && B >= 1 &&
            B * (int64_t)max_len * E * 4 < (int64_t)INT_MAX;
 }
 
 int capdec_launch_fused_layers(const capdec_fused_args& a, int E, hipStream_t s) {
-    CAPDEC_REQUIRE(E == 512);
+    CAPDEC_REQUIRE(E == 512 && a.L >= 1 && a.L <= 2);
     using C = FT<512>;
     constexpr size_t lds_bytes = (size_t)C::LDS_FLOATS * sizeof(float);
     int dev = 0;
@@ -588,8 +743,7 @@ int capdec_launch_fused_layers(const capdec_fused_args& a, int E, hipStream_t s)
             g_attr_done[dev] = true;
         }
     }
-    const int nteams = a.extra_teams + a.main_teams;
-    const unsigned grid = (unsigned)((nteams + 7) / 8) * 64u;
+    const unsigned grid = (unsigned)((a.teams + 7) / 8) * 64u;
     hipLaunchKernelGGL(decode_layers_team_kernel<512>, dim3(grid), dim3(FT_THREADS), lds_bytes, s, a);
     CAPDEC_LAUNCH_CHECK();
     return 0;

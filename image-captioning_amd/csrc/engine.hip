@@ -754,15 +754,13 @@ struct DecodeWs {
     int32_t *fin;            // [max_len] captions whose <EOS> came at step t
     // all layers of a step in one launch (decode_fused.hip; S == 1 and a supported shape only, otherwise null)
     float *tq, *tctx, *ty, *th, *tz;    // [teams][32][E] exchange buffers of the teams
-    unsigned* ctr;           // [max_len][teams + 1][32] arrival counters, then 32 words whose first is the error word
-    int32_t* infected;       // [B] the sample's rows are all in the re-run list of the next step
-    int fused_extra_cap, fused_teams;
+    float *sctx, *sy, *sh, *sz;         // [teams][16][E] the same of their side rows (earlier <PAD> positions)
+    unsigned* ctr;           // [max_len][teams][32] arrival counters, then 32 words whose first is the error word
+    int32_t *pcount, *plist; // [teams], [teams][16]: <PAD> positions generated by the team's samples
+    int fused_teams;
 };
 
 static int default_extra_cap(int B) { return ((B / 4 > 64 ? B / 4 : 64) + 63) / 64 * 64; }
-
-// re-run rows the one-launch layers take: their teams must all be resident at once (they wait for one another)
-static int fused_extra_rows(int extra_cap) { return extra_cap < 512 ? extra_cap : 512; }
 
 static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, int extra_cap, void* base,
                            DecodeWs* w) {
@@ -802,19 +800,20 @@ static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, 
     d.rowmap = c.take<int32_t>((size_t)max_len * (B + extra_cap));
     d.nrows = c.take<int32_t>((size_t)max_len + 1);
     d.fin = c.take<int32_t>((size_t)max_len);
-    d.tq = d.tctx = d.ty = d.th = d.tz = nullptr;
+    d.tq = d.tctx = d.ty = d.th = d.tz = d.sctx = d.sy = d.sh = d.sz = nullptr;
     d.ctr = nullptr;
-    d.infected = nullptr;
-    d.fused_extra_cap = d.fused_teams = 0;
+    d.pcount = d.plist = nullptr;
+    d.fused_teams = 0;
     if (S == 1 && capdec_fused_layers_supported(m->E, m->H, m->L, B, max_len)) {
-        d.fused_extra_cap = fused_extra_rows(extra_cap);
-        d.fused_teams = (d.fused_extra_cap + CAPDEC_FUSED_ROWS - 1) / CAPDEC_FUSED_ROWS +
-                        (B + CAPDEC_FUSED_ROWS - 1) / CAPDEC_FUSED_ROWS;
+        d.fused_teams = (B + CAPDEC_FUSED_ROWS - 1) / CAPDEC_FUSED_ROWS;
         const size_t TE = (size_t)d.fused_teams * CAPDEC_FUSED_ROWS * m->E;
+        const size_t SE = (size_t)d.fused_teams * CAPDEC_FUSED_SIDE_ROWS * m->E;
         d.tq = c.take<float>(TE); d.tctx = c.take<float>(TE); d.ty = c.take<float>(TE);
         d.th = c.take<float>(TE); d.tz = c.take<float>(TE);
-        d.ctr = c.take<unsigned>(((size_t)max_len * (d.fused_teams + 1) + 1) * 32);
-        d.infected = c.take<int32_t>((size_t)B);
+        d.sctx = c.take<float>(SE); d.sy = c.take<float>(SE); d.sh = c.take<float>(SE); d.sz = c.take<float>(SE);
+        d.ctr = c.take<unsigned>(((size_t)max_len * d.fused_teams + 1) * 32);
+        d.pcount = c.take<int32_t>((size_t)d.fused_teams);
+        d.plist = c.take<int32_t>((size_t)d.fused_teams * CAPDEC_FUSED_SIDE_ROWS);
     }
     if (w) *w = d;
     return c.off;
@@ -822,7 +821,7 @@ static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, 
 
 __global__ void cached_init_kernel(int32_t* tok, int64_t ldtok, int32_t* done, int32_t* first_pad, int64_t* out_ids,
                                    int32_t* out_len, int32_t* dirty, int32_t* rowmap, int32_t* nrows,
-                                   int32_t* fin, int B, int max_len, int sos, int32_t* infected) {
+                                   int32_t* fin, int B, int max_len, int sos, int32_t* pcount, int nteams) {
     const int n = B * max_len;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     for (int idx = tid; idx < n; idx += nth) out_ids[idx] = -1;
@@ -832,11 +831,12 @@ __global__ void cached_init_kernel(int32_t* tok, int64_t ldtok, int32_t* done, i
         first_pad[b] = INT_MAX;
         out_len[b] = 0;
         if (dirty) dirty[b] = 0;
-        if (infected) infected[b] = 0;
         rowmap[b] = b * max_len;            // step 0: position 0 of every sample
     }
     for (int t = tid; t <= max_len; t += nth) nrows[t] = B;
     for (int t = tid; t < max_len; t += nth) fin[t] = 0;
+    if (pcount)
+        for (int t = tid; t < nteams; t += nth) pcount[t] = 0;
 }
 
 // One wavefront per sample: pick the token (as greedy_advance_kernel), then prepare step t+1: the sample's new row and,
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(256) void cached_advance_kernel(const float* __rest
                                                              const float* __restrict__ pe, int E, int V,
                                                              float* __restrict__ x_next, int32_t* rowmap_next,
                                                              int32_t* nrows_next, int extra_cap, int32_t* fin,
-                                                             int32_t* infected, const unsigned* fuse_err) {
+                                                             int32_t* pcount, int32_t* plist, const unsigned* fuse_err) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     int fin_before = 0;
@@ -888,18 +888,21 @@ __global__ __launch_bounds__(256) void cached_advance_kernel(const float* __rest
                 out_ids[(int64_t)b * max_len + n] = i;
                 out_len[b] = n + 1;
                 if (i == 0 && first_pad[b] == INT_MAX) first_pad[b] = t + 1;
+                if (i == 0 && pcount) {
+                    // one launch for all layers: the <PAD> position joins the side rows of its sample's team
+                    const int team = b / CAPDEC_FUSED_ROWS;
+                    const int slot = atomicAdd(&pcount[team], 1);
+                    if (slot < CAPDEC_FUSED_SIDE_ROWS) plist[team * CAPDEC_FUSED_SIDE_ROWS + slot] = b * max_len + t + 1;
+                    else if (dirty && dirty[b] == 0) dirty[b] = 1;
+                }
             }
         }
         p0 = first_pad[b];
         running = !done[b];          // a finished row's later tokens are discarded: no need to keep it exact
-        // one launch for all layers (infected != NULL): the re-run list holds EVERY row of such a sample, its new
-        // position t+1 included, so that the teams of the list depend on no other team
-        if (fuse_err && fuse_err[0] && dirty) dirty[b] = 2;      // a wait of that launch ran out: redo the sample exactly
+        if (fuse_err && fuse_err[0] && dirty) dirty[b] = 2;      // a wait of the one-launch layers ran out: redo the sample exactly
         if (x_next) {
             rowmap_next[b] = b * max_len + t + 1;
-            const bool listed = p0 != INT_MAX && running && t + 1 > p0;
-            if (listed) base = atomicAdd(nrows_next, t + 1 - p0 + (infected ? 1 : 0)) - B;
-            if (infected) infected[b] = listed ? 1 : 0;
+            if (!pcount && p0 != INT_MAX && running && t + 1 > p0) base = atomicAdd(nrows_next, t + 1 - p0) - B;
         }
     }
     if (!x_next) return;
@@ -913,15 +916,15 @@ __global__ __launch_bounds__(256) void cached_advance_kernel(const float* __rest
         f32x4* dst = reinterpret_cast<f32x4*>(x_next + (int64_t)b * E);
         for (int c = lane; c < nv; c += 64) dst[c] = src[c] + pp[c];
     }
-    if (p0 == INT_MAX || !running || t + 1 <= p0) return;
-    const int cnt = t + 1 - p0 + (infected ? 1 : 0);      // positions p0 .. t (.. t+1) are re-run at step t+1
+    if (pcount || p0 == INT_MAX || !running || t + 1 <= p0) return;
+    const int cnt = t + 1 - p0;      // positions p0 .. t are re-run at step t+1
     if (base + cnt > extra_cap && lane == 0 && dirty && dirty[b] == 0) dirty[b] = 1;   // list full: the host re-decodes this row exactly
     for (int k = 0; k < cnt; ++k) {
         const int slot = base + k;
         if (slot >= extra_cap) break;
         const int p = p0 + k;
         if (lane == 0) rowmap_next[B + slot] = b * max_len + p;
-        const int id = p == t + 1 ? i : tok[(int64_t)b * ldtok + p];
+        const int id = tok[(int64_t)b * ldtok + p];
         const f32x4* src = reinterpret_cast<const f32x4*>(emb + (int64_t)id * E);
         const f32x4* pp = reinterpret_cast<const f32x4*>(pe + (int64_t)p * E);
         f32x4* dst = reinterpret_cast<f32x4*>(x_next + (int64_t)(B + slot) * E);
@@ -999,17 +1002,14 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
     CAPDEC_REQUIRE(!(flags & CAPDEC_DECODE_FOLD_MEMORY) || fold);      // forced but unavailable (S < 3 or E not built)
 
     hipLaunchKernelGGL(cached_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, w.first_pad, out_ids,
-                       out_len, out_dirty, w.rowmap, w.nrows, w.fin, B, max_len, sos, w.infected);
+                       out_len, out_dirty, w.rowmap, w.nrows, w.fin, B, max_len, sos, w.pcount, w.fused_teams);
     CAPDEC_LAUNCH_CHECK();
     CAPDEC_TRY(capdec_embed_pe(w.tok, 1, ldtok, m->emb, m->pe, 0, B, 1, E, V, w.x, stream));
     // all layers of a step in one launch (single memory row, supported shape): the arrival counters of every step start at zero
     const bool fused = s1 && w.ctr && !(flags & CAPDEC_DECODE_NO_FUSED_LAYERS);
-    const size_t ctr_step = (size_t)(w.fused_teams + 1) * 32;
+    const size_t ctr_step = (size_t)w.fused_teams * 32;
     unsigned* fuse_err = fused ? w.ctr + (size_t)max_len * ctr_step : nullptr;
-    if (fused) {
-        CAPDEC_TRY((int)hipMemsetAsync(w.ctr, 0, ((size_t)max_len * ctr_step + 32) * sizeof(unsigned), s));
-        extra_cap = w.fused_extra_cap;
-    }
+    if (fused) CAPDEC_TRY((int)hipMemsetAsync(w.ctr, 0, ((size_t)max_len * ctr_step + 32) * sizeof(unsigned), s));
 
     if (s1) {
         // softmax over one key is exactly 1, so the block's output is W_o(W_v enc + b_v) + b_o for every
@@ -1045,11 +1045,12 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
                 f.vc = w.vc + (size_t)l * BE * max_len;
             }
             fa.L = L; fa.B = B; fa.max_len = max_len; fa.Tk = t + 1;
-            fa.extra_teams = (w.fused_extra_cap + CAPDEC_FUSED_ROWS - 1) / CAPDEC_FUSED_ROWS;
-            fa.main_teams = (B + CAPDEC_FUSED_ROWS - 1) / CAPDEC_FUSED_ROWS;
+            fa.teams = w.fused_teams;
             fa.cache_bytes = (int)(BE * max_len * sizeof(float));
             fa.x = w.x; fa.q = w.tq; fa.f_ctx = w.tctx; fa.f_y = w.ty; fa.f_h = w.th; fa.f_z = w.tz;
-            fa.tok = w.tok; fa.ldtok = ldtok; fa.rowmap = map; fa.nrows = rows; fa.infected = w.infected;
+            fa.s_ctx = w.sctx; fa.s_y = w.sy; fa.s_h = w.sh; fa.s_z = w.sz;
+            fa.tok = w.tok; fa.ldtok = ldtok; fa.nrows = rows; fa.done = w.done;
+            fa.pcount = w.pcount; fa.plist = w.plist; fa.emb = m->emb; fa.pe = m->pe;
             fa.ctr = w.ctr + (size_t)t * ctr_step; fa.err = fuse_err;
             CAPDEC_TRY(capdec_launch_fused_layers(fa, E, s));
         }
@@ -1116,7 +1117,7 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
         hipLaunchKernelGGL(cached_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
                            eos, w.tok, ldtok, w.done, w.first_pad, out_ids, out_len, out_dirty, m->emb, m->pe, E, V,
                            last ? nullptr : w.x, last ? nullptr : w.rowmap + (size_t)(t + 1) * Mcap,
-                           last ? nullptr : w.nrows + t + 1, extra_cap, w.fin, fused ? w.infected : nullptr, fuse_err);
+                           last ? nullptr : w.nrows + t + 1, extra_cap, w.fin, fused ? w.pcount : nullptr, w.plist, fuse_err);
         CAPDEC_LAUNCH_CHECK();
     }
     return 0;

@@ -1,7 +1,7 @@
 // Times the one-launch decoder layers of a cached decode step alone (cfg2 shapes: B rows, E=512, L layers) and prints
 // the stage timestamps of one team.  Build (tools/exp/build_probes.sh):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCAPDEC_FUSED_TRACE tools/exp/fused_step_probe.hip -o tools/exp/bin/fused_step_probe
-// Run: fused_step_probe [B] [L] [Tk] [reps]
+// Run: fused_step_probe [B] [L] [Tk] [reps] [pad positions per fourth team]
 #include "../../image-captioning_amd/csrc/decode_fused.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -32,7 +32,8 @@ int main(int argc, char** argv) {
     const int L = argc > 2 ? atoi(argv[2]) : 2;
     const int Tk = argc > 3 ? atoi(argv[3]) : 10;
     const int reps = argc > 4 ? atoi(argv[4]) : 50;
-    const int E = 512, max_len = 20, extra_teams = 8;
+    const int E = 512, max_len = 20;
+    const int npad = argc > 5 ? atoi(argv[5]) : 0;      // <PAD> positions (side rows) in every fourth team
     std::mt19937 g(1);
     capdec_fused_args a{};
     const float ws = 0.044f;
@@ -46,31 +47,40 @@ int main(int argc, char** argv) {
         f.kc = dev_random((size_t)B * max_len * E, 1.f, g);
         f.vc = dev_random((size_t)B * max_len * E, 1.f, g);
     }
-    const int main_teams = (B + 31) / 32, nteams = main_teams + extra_teams;
-    const int Mcap = B + extra_teams * 32;
+    const int nteams = (B + 31) / 32;
     a.L = L; a.B = B; a.max_len = max_len; a.Tk = Tk;
-    a.extra_teams = extra_teams; a.main_teams = main_teams;
+    a.teams = nteams;
     a.cache_bytes = (int)((size_t)B * max_len * E * 4);
-    a.x = dev_random((size_t)Mcap * E, 1.f, g);
-    const size_t TE = (size_t)nteams * 32 * E;
+    a.x = dev_random((size_t)B * E, 1.f, g);
+    const size_t TE = (size_t)nteams * 32 * E, SE = (size_t)nteams * 16 * E;
     a.q = dev_random(TE, 1.f, g); a.f_ctx = dev_random(TE, 1.f, g); a.f_y = dev_random(TE, 1.f, g);
     a.f_h = dev_random(TE, 1.f, g); a.f_z = dev_random(TE, 1.f, g);
-    std::vector<int32_t> tok((size_t)B * (max_len + 1), 5), rowmap(Mcap, 0), nrows(1, B), infected(B, 0);
-    for (int b = 0; b < B; ++b) rowmap[b] = b * max_len + Tk - 1;
-    int32_t *dtok, *dmap, *dn, *dinf;
+    a.s_ctx = dev_random(SE, 1.f, g); a.s_y = dev_random(SE, 1.f, g); a.s_h = dev_random(SE, 1.f, g); a.s_z = dev_random(SE, 1.f, g);
+    a.emb = dev_random((size_t)16 * E, 1.f, g); a.pe = dev_random((size_t)max_len * E, 1.f, g);
+    std::vector<int32_t> tok((size_t)B * (max_len + 1), 5), nrows(1, B), done(B, 0), pcount(nteams, 0), plist((size_t)nteams * 16, 0);
+    for (int t = 0; t < nteams; t += 4) {
+        pcount[t] = npad;
+        for (int k = 0; k < npad && k < 16; ++k) {
+            const int b = t * 32 + (k % 32), pos = k % (Tk > 1 ? Tk - 1 : 1);
+            plist[t * 16 + k] = b * max_len + pos;
+            tok[(size_t)b * (max_len + 1) + pos] = 0;
+        }
+    }
+    int32_t *dtok, *dn, *ddone, *dpc, *dpl;
     CK(hipMalloc(&dtok, tok.size() * 4)); CK(hipMemcpy(dtok, tok.data(), tok.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMalloc(&dmap, rowmap.size() * 4)); CK(hipMemcpy(dmap, rowmap.data(), rowmap.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dn, 4)); CK(hipMemcpy(dn, nrows.data(), 4, hipMemcpyHostToDevice));
-    CK(hipMalloc(&dinf, B * 4)); CK(hipMemcpy(dinf, infected.data(), B * 4, hipMemcpyHostToDevice));
-    a.tok = dtok; a.ldtok = max_len + 1; a.rowmap = dmap; a.nrows = dn; a.infected = dinf;
-    const size_t ctr_words = (size_t)(nteams + 1) * 32 + 32;
+    CK(hipMalloc(&ddone, B * 4)); CK(hipMemcpy(ddone, done.data(), B * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dpc, nteams * 4)); CK(hipMemcpy(dpc, pcount.data(), nteams * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dpl, plist.size() * 4)); CK(hipMemcpy(dpl, plist.data(), plist.size() * 4, hipMemcpyHostToDevice));
+    a.tok = dtok; a.ldtok = max_len + 1; a.nrows = dn; a.done = ddone; a.pcount = dpc; a.plist = dpl;
+    const size_t ctr_words = (size_t)nteams * 32 + 32;
     unsigned* ctr;
     CK(hipMalloc(&ctr, ctr_words * 4));
-    a.ctr = ctr; a.err = ctr + (size_t)(nteams + 1) * 32;
+    a.ctr = ctr; a.err = ctr + (size_t)nteams * 32;
     unsigned long long* trace;
     CK(hipMalloc(&trace, 8 * 64 * 8));
     CK(hipMemset(trace, 0, 8 * 64 * 8));
-    a.trace = trace; a.trace_team = extra_teams + main_teams / 2;
+    a.trace = trace; a.trace_team = (nteams / 2) / 4 * 4;
     hipStream_t s;
     CK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
@@ -88,7 +98,7 @@ int main(int argc, char** argv) {
     }
     unsigned err = 0;
     CK(hipMemcpy(&err, a.err, 4, hipMemcpyDeviceToHost));
-    printf("B=%d L=%d Tk=%d: %.1f us per launch (best %.1f), err=%u\n", B, L, Tk, total / reps * 1e3f, best * 1e3f, err);
+    printf("B=%d L=%d Tk=%d side rows %d: %.1f us per launch (best %.1f), err=%u\n", B, L, Tk, npad, total / reps * 1e3f, best * 1e3f, err);
     std::vector<unsigned long long> t(8 * 64);
     CK(hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost));
     int n = 0;
