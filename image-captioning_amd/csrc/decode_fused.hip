@@ -72,8 +72,8 @@ struct FT {
     static constexpr int OFF_RS = OFF_R + 32 * NC;    // [NC/4][16][4] the same of the side rows
     static constexpr int OFF_CST = OFF_RS + 16 * NC;  // [16][DK+4] attention outputs before they are stored
     static constexpr int OFF_PART = OFF_CST + 16 * CST_LD;      // [2][8][32] LayerNorm partial sums
-    static constexpr int OFF_SC = OFF_PART + 2 * FT_WAVES * 32; // [8][64] score rows
-    static constexpr int OFF_META = OFF_SC + FT_WAVES * 64;     // ints: row descriptors, wait flag
+    static constexpr int OFF_SC = OFF_PART + 2 * FT_WAVES * 32; // [8][2][64] probability rows (two (row, head) pairs per wavefront)
+    static constexpr int OFF_META = OFF_SC + FT_WAVES * 128;    // ints: row descriptors, wait flag
     static constexpr int LDS_FLOATS = OFF_META + 2 * 32 + 4 * 16 + 16;
     static_assert(NH == 2 && NT >= 1 && KW == NC && NC == 64, "team kernel built for E = 512");
 };
@@ -107,10 +107,15 @@ __device__ __forceinline__ void issue_half(const float* __restrict__ W, int memb
     float* dst = slot + wave * C::WSLAB;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, E * E * 4, 0x00020000);
     const int base = ((member * C::NC) * E + wave * C::KW + half * 32) * 4;      // uniform
+#ifndef FT_W_AUX
+#define FT_W_AUX 0
+#endif
+#ifndef FT_EXPERIMENT_NO_DMA      // timing experiment only (tools/exp): the contractions then read whatever LDS holds
 #pragma unroll
     for (int p = 0; p < C::PIECES; ++p)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + p * 256), 16,
-                                             (p & 1) ? lo.odd : lo.even, base + p * 8 * E * 4, 0, 0);
+                                                 (p & 1) ? lo.odd : lo.even, base + p * 8 * E * 4, 0, FT_W_AUX);
+#endif
 }
 
 // 32 rows: lane (r, h) holds a[kc] = X[r][k0 + kc*8 + 4h + {0..3}]; MFMA m of chunk kc sums k in {kc*8+m, kc*8+4+m}
@@ -236,31 +241,43 @@ __device__ __forceinline__ f32x4 sum_partials(const float* lds, int i, int sl) {
     return v;
 }
 
-// Every storing wavefront drains its stores, the workgroup meets, one lane publishes.
-__device__ __forceinline__ void team_signal(unsigned* ctr) {
+// Workgroup barrier that orders LDS traffic only.  (__syncthreads() also waits for every global access of the
+// wavefront - weight loads in flight, the acknowledgement of a flag store - which nothing here needs.)
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Hand-off flags of a team: one word per member in one 128-byte line, holding the number of the member's last
+// finished operation.  Publishing: every storing wavefront drains its stores, the workgroup meets, one lane stores the
+// flag write-through.  (An atomic add on a shared counter costs its issuer about 3.5 us until it is acknowledged.)
+__device__ __forceinline__ void team_signal(unsigned* flags, int member, unsigned epoch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wg_barrier();
+    if (threadIdx.x == 0) __hip_atomic_store(flags + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// One lane polls (relaxed, L1-bypassing), the workgroup meets behind it; false (for every thread) when the spin ran out.
-__device__ __forceinline__ bool team_wait(unsigned* ctr, unsigned target, unsigned* err, int* flag) {
-    if (threadIdx.x == 0) {
+// Lanes 0..7 of the first wavefront poll the eight flags (relaxed, L1-bypassing), the workgroup meets behind them;
+// false (for every thread) when the spin ran out.
+__device__ __forceinline__ bool team_wait(unsigned* flags, unsigned epoch, unsigned* err, int* flag) {
+#ifdef FT_EXPERIMENT_NO_WAIT      // timing experiment only (tools/exp): results are garbage
+    wg_barrier();
+    return true;
+#endif
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
         unsigned spins = 0;
         int ok = 1;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        for (;;) {
+            const unsigned v = lane < FT_TEAM ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+            if (__all(v >= epoch)) break;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > FT_SPIN_LIMIT) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
             }
         }
-        *flag = ok;
+        if (lane == 0) flag[epoch & 1] = ok;
     }
-    __syncthreads();
-    const bool ok = *flag != 0;
-    __syncthreads();             // the flag may be rewritten by the next wait only after everyone has read it
-    return ok;
+    wg_barrier();
+    return flag[epoch & 1] != 0;     // (two words in turn: the next wait writes the other one)
 }
 
 // Fragments of a [k/4][ROWS][4] exchange block: lane (row, g) of wavefront w loads the 16-byte slots w*KW/4 + kf*G + g
@@ -290,7 +307,7 @@ __device__ __forceinline__ void ln_frags(f32x4 (&a)[NF], const float* __restrict
     float* p = part + pb * (FT_WAVES * 32);
     pb ^= 1;
     if (g == 0) p[wave * 32 + row] = s;
-    __syncthreads();
+    wg_barrier();
     float tot = 0.f;
 #pragma unroll
     for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 32 + row];
@@ -306,7 +323,7 @@ __device__ __forceinline__ void ln_frags(f32x4 (&a)[NF], const float* __restrict
     p = part + pb * (FT_WAVES * 32);
     pb ^= 1;
     if (g == 0) p[wave * 32 + row] = q;
-    __syncthreads();
+    wg_barrier();
     tot = 0.f;
 #pragma unroll
     for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 32 + row];
@@ -378,7 +395,7 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
         ss_pos[sr] = pos;
         ss_act[sr] = (sr < n && pos < pos_new && !A.done[b]) ? 1 : 0;
     }
-    __syncthreads();
+    wg_barrier();
     bool side = false;
 #pragma unroll
     for (int i = 0; i < FT_SIDE; ++i) side |= ss_act[i] != 0;
@@ -414,7 +431,8 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
 #pragma unroll
             for (int kc = 0; kc < C::NA; ++kc) a[kc] = *reinterpret_cast<const f32x4*>(xr + kc * 8);
         } else {
-            if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
+            if (!team_wait(tctr, nsig, A.err, s_ok)) return;
+            if (wave == 0) issue_half<E>(ly.wq, member, wave, lo, 1, slot1);
             load_frags<E, C::NA, 5>(FT_RS(A.f_z + tb, blk), wave, lane, a);
             if (side_kv) load_frags<E, C::NS, 4>(FT_RS(A.s_z + tsb, sblk), wave, lane, as);
             ln_frags<E, C::NA, 5>(a, A.ly[l - 1].n3g, A.ly[l - 1].n3b, part, pb, wave, lane);
@@ -435,7 +453,7 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 write_partial<E>(lds, wave, lane, acc[p]);
-                __syncthreads();
+                wg_barrier();
                 const float* bias = p == 0 ? ly.bq : (p == 1 ? ly.bk : ly.bv);
                 const int col = member * C::NC + sb * 4;
                 const f32x4 v = sum_partials<E>(lds, ib, sb) + *reinterpret_cast<const f32x4*>(bias + col);
@@ -443,7 +461,7 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
                 else if (s_flags[ib] & 1)
                     store_sc1(FT_RS(p == 1 ? ly.kc : ly.vc, cache_bytes),
                               ((unsigned)(s_b[ib] * A.max_len + pos_new) * (unsigned)E + col) * 4u, v);
-                __syncthreads();
+                wg_barrier();
             }
         }
         if (side_kv) {
@@ -456,97 +474,112 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 write_partial_side<E>(lds, wave, lane, accs[p]);
-                __syncthreads();
+                wg_barrier();
                 if (sthr && ss_act[jb]) {
                     const int col = member * C::NC + tb_ * 4;
                     const f32x4 v = sum_partials<E>(lds, jb, tb_) + *reinterpret_cast<const f32x4*>((p == 0 ? ly.bk : ly.bv) + col);
                     store_sc1(FT_RS(p == 0 ? ly.kc : ly.vc, cache_bytes), ((unsigned)ss_map[jb] * (unsigned)E + col) * 4u, v);
                 }
-                __syncthreads();
+                wg_barrier();
             }
         }
         FT_MARK();                               // q, k, v stored
-        team_signal(tctr);
+        team_signal(tctr, member, nsig + 1);
         ++nsig;
-        issue_half<E>(ly.wo, member, wave, lo, 1, slot1);
+        // (the wavefront that polls issues its part after the poll: its loads return in order, so a load in flight
+        //  would hold the poll's answer back)
+        if (wave != 0) issue_half<E>(ly.wo, member, wave, lo, 1, slot1);
         FT_MARK();                               // signalled
 
         // ---- self-attention: member = (head, half of the rows), two (row, head) pairs per wavefront -----------
-        if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
+        if (!team_wait(tctr, nsig, A.err, s_ok)) return;
+        if (wave == 0) issue_half<E>(ly.wo, member, wave, lo, 1, slot1);
         FT_MARK();                               // team has q, k, v
         {
-            constexpr int NM = C::DK / 16, LPV = C::DK / 4, NGRP = 64 / LPV;
+            // The two pairs of a wavefront share every instruction: lanes 0-31 serve row 2w, lanes 32-63 row 2w+1 of the
+            // member's 16 rows, both for head hd.  Scores: 4 lanes per key, 8 keys per pass and pair, kept in registers;
+            // softmax over the key lanes of the half-wavefront; context: one lane per 16 bytes of the head, the keys in
+            // turn.  The loads do not depend on one another, so queries, keys and values are in flight together.
+            constexpr int NM = C::DK / 16, LPV = C::DK / 4;
+            static_assert(LPV == 32, "one half-wavefront per head row");
             const int hd = member >> 1, rbase = (member & 1) * 16;
-            float* sc = lds + C::OFF_SC + wave * 64;
+            const int pr = lane >> 5, l32 = lane & 31;
+            const int li = 2 * wave + pr, i = rbase + li;
             float* cst = lds + C::OFF_CST;
             const float scale = sqrtf((float)C::DK);
             const __amdgpu_buffer_rsrc_t rs_q = FT_RS(A.q + tb, blk);
             const __amdgpu_buffer_rsrc_t rs_k = FT_RS(ly.kc, cache_bytes);
             const __amdgpu_buffer_rsrc_t rs_v = FT_RS(ly.vc, cache_bytes);
-#pragma unroll 1
-            for (int it = 0; it < 2; ++it) {
-                const int li = 2 * wave + it, i = rbase + li;
-                const int b = s_b[i];
-                const bool pad_row = (s_flags[i] & 2) != 0;
-                const int nkeys = A.Tk;          // the newest position sees every key, <PAD> query or not
-                const unsigned kb = ((unsigned)(b * A.max_len) * (unsigned)E + (unsigned)(hd * C::DK)) * 4u;
-                float sum = 1.f;
-                if (!pad_row) {
-                    const int prt = lane & 3, kl = lane >> 2;
-                    f32x4 qreg[NM];
+            const int b = s_b[i];
+            const bool pad_row = (s_flags[i] & 2) != 0;
+            const int nkeys = A.Tk;              // the newest position sees every key, <PAD> query or not
+            const unsigned kb = ((unsigned)(b * A.max_len) * (unsigned)E + (unsigned)(hd * C::DK)) * 4u;
+            const int prt = l32 & 3, kl = l32 >> 2;
+            f32x4 qreg[NM];
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) qreg[m] = load_sc1(FT_RS(A.q + tb, blk), (unsigned)((i * E + hd * C::DK + 4 * prt + 16 * m) * 4));
-                    for (int j0 = 0; j0 < nkeys; j0 += 16) {
-                        const int j = j0 + kl;
-                        float d = 0.f;
-                        if (j < nkeys) {
+            for (int m = 0; m < NM; ++m) qreg[m] = load_sc1(rs_q, (unsigned)((i * E + hd * C::DK + 4 * prt + 16 * m) * 4));
+            // lane kl of pass ps holds the score of key 8*ps + kl (max_len <= 64: 8 passes)
+            float mx = -INFINITY;
+            float sreg[8];
 #pragma unroll
-                            for (int m = 0; m < NM; ++m) {
-                                const f32x4 kk = load_sc1(rs_k, kb + (unsigned)((j * E + 4 * prt + 16 * m) * 4));
-                                d += qreg[m][0] * kk[0] + qreg[m][1] * kk[1] + qreg[m][2] * kk[2] + qreg[m][3] * kk[3];
-                            }
-                        }
-                        d += __shfl_xor(d, 1, 64);
-                        d += __shfl_xor(d, 2, 64);
-                        if (prt == 0 && j < nkeys) sc[j] = d / scale;
+            for (int ps = 0; ps < 8; ++ps) {
+                sreg[ps] = -INFINITY;
+                const int j = 8 * ps + kl;
+                if (8 * ps < nkeys) {            // uniform
+                    float d = 0.f;
+                    const int jj = j < nkeys ? j : nkeys - 1;
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        const f32x4 kk = load_sc1(rs_k, kb + (unsigned)((jj * E + 4 * prt + 16 * m) * 4));
+                        d += qreg[m][0] * kk[0] + qreg[m][1] * kk[1] + qreg[m][2] * kk[2] + qreg[m][3] * kk[3];
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    float mx = -INFINITY;
-                    for (int j = lane; j < nkeys; j += 64) mx = fmaxf(mx, sc[j]);
-                    mx = wave_max(mx);
-                    float s = 0.f;
-                    for (int j = lane; j < nkeys; j += 64) {
-                        const float e = expf(sc[j] - mx);
-                        sc[j] = e;
-                        s += e;
-                    }
-                    sum = wave_sum(s);
-                } else {
-                    // every score of a <PAD> query row is the same fill value: uniform over all Tk keys
-                    for (int j = lane; j < nkeys; j += 64) sc[j] = 1.f;
-                    sum = (float)nkeys;
+                    d += __shfl_xor(d, 1, 64);
+                    d += __shfl_xor(d, 2, 64);
+                    if (j < nkeys) sreg[ps] = d / scale;
+                    mx = fmaxf(mx, sreg[ps]);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const int grp = lane / LPV, dl = lane - grp * LPV;
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                for (int j = grp; j < nkeys; j += NGRP) {
-                    const float p = sc[j] / sum;
-                    const f32x4 vv = load_sc1(rs_v, kb + (unsigned)((j * E + 4 * dl) * 4));
-                    o += vv * p;
-                }
-#pragma unroll
-                for (int off = LPV; off < 64; off <<= 1) {
-                    o[0] += __shfl_xor(o[0], off, 64);
-                    o[1] += __shfl_xor(o[1], off, 64);
-                    o[2] += __shfl_xor(o[2], off, 64);
-                    o[3] += __shfl_xor(o[3], off, 64);
-                }
-                if (grp == 0) *reinterpret_cast<f32x4*>(cst + li * C::CST_LD + 4 * dl) = o;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the score row is rewritten by the next pair
             }
-            __syncthreads();
-            for (int idx = tid; idx < 16 * LPV; idx += FT_THREADS) {
-                const int i16 = idx & 15, sl = idx >> 4;
+#pragma unroll
+            for (int o = 4; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const float e = (8 * ps + kl < nkeys) ? expf(sreg[ps] - mx) : 0.f;
+                sreg[ps] = e;
+                sum += e;
+            }
+#pragma unroll
+            for (int o = 4; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            if (pad_row) {
+                // every score of a <PAD> query row is the same fill value: uniform over all Tk keys
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) sreg[ps] = 1.f;
+                sum = (float)nkeys;
+            }
+            // probabilities through LDS: a wavefront-private row of 64 floats per pair
+            float* prow = lds + C::OFF_SC + wave * 128 + pr * 64;
+            if (prt == 0) {
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps)
+                    if (8 * ps + kl < nkeys) prow[8 * ps + kl] = sreg[ps] / sum;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            for (int j0 = 0; j0 < nkeys; j0 += 8) {
+                f32x4 vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int jj = j0 + u < nkeys ? j0 + u : nkeys - 1;
+                    vv[u] = load_sc1(rs_v, kb + (unsigned)((jj * E + 4 * l32) * 4));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u < nkeys) o += vv[u] * prow[j0 + u];
+            }
+            *reinterpret_cast<f32x4*>(cst + li * C::CST_LD + 4 * l32) = o;
+            wg_barrier();
+            {
+                const int i16 = tid & 15, sl = tid >> 4;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(cst + i16 * C::CST_LD + sl * 4);
                 store_sc1(FT_RS(A.f_ctx + tb, blk), (unsigned)(((hd * LPV + sl) * 32 + rbase + i16) * 16), v);
             }
@@ -562,13 +595,13 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
             }
         }
         FT_MARK();                               // attention stored
-        team_signal(tctr);
+        team_signal(tctr, member, nsig + 1);
         ++nsig;
         FT_MARK();
         const bool side_l0 = side && l == 0;     // the side rows walk layer 0 behind the attention
 
         // ---- output projection + residual ---------------------------------------------------------------------
-        if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
+        if (!team_wait(tctr, nsig, A.err, s_ok)) return;
         FT_MARK();                               // team has the attention output
         load_frags<E, C::NA, 5>(FT_RS(A.f_ctx + tb, blk), wave, lane, a);
         if (side_l0) load_frags<E, C::NS, 4>(FT_RS(A.s_ctx + tsb, sblk), wave, lane, as);
@@ -579,14 +612,14 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
             gemm_stream<E, 1, 1, 1>(lds, W1, ly.w1, member, wave, lane, lo, a, acc, side_l0, as, accs);
             FT_MARK();                           // output projection contracted
             write_partial<E>(lds, wave, lane, acc[0]);
-            __syncthreads();
+            wg_barrier();
             const f32x4 v = sum_partials<E>(lds, ia, sa) + *reinterpret_cast<const f32x4*>(ly.bo + member * C::NC + sa * 4) +
                             R[sa * 32 + ia];
             store_sc1(FT_RS(A.f_y + tb, blk), frag_off, v);
             if (side_l0) {
-                __syncthreads();
+                wg_barrier();
                 write_partial_side<E>(lds, wave, lane, accs[0]);
-                __syncthreads();
+                wg_barrier();
                 if (sthr) {
                     // residual: the side row's own input, embedding + position
                     const int col = member * C::NC + ta * 4;
@@ -599,9 +632,9 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
             }
         }
         FT_MARK();
-        team_signal(tctr);
+        team_signal(tctr, member, nsig + 1);
         ++nsig;
-        issue_half<E>(ly.w1, member, wave, lo, 1, slot1);
+        if (wave != 0) issue_half<E>(ly.w1, member, wave, lo, 1, slot1);
         FT_MARK();
 
         // ---- LayerNorm 1, + the cross-attention block (one vector per sample), LayerNorm 2, fc1 + ReLU ---------
@@ -617,7 +650,8 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
                 for (int kf = 0; kf < C::NS; ++kf) cadds[kf] = *reinterpret_cast<const f32x4*>(cs + kf * 16);
             }
         }
-        if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
+        if (!team_wait(tctr, nsig, A.err, s_ok)) return;
+        if (wave == 0) issue_half<E>(ly.w1, member, wave, lo, 1, slot1);
         FT_MARK();                               // team has y
         load_frags<E, C::NA, 5>(FT_RS(A.f_y + tb, blk), wave, lane, a);
         if (side_l0) load_frags<E, C::NS, 4>(FT_RS(A.s_y + tsb, sblk), wave, lane, as);
@@ -647,14 +681,14 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
             gemm_stream<E, 1, 1, 1>(lds, W1, ly.w2, member, wave, lane, lo, a, acc, side_l0, as, accs);
             FT_MARK();
             write_partial<E>(lds, wave, lane, acc[0]);
-            __syncthreads();
+            wg_barrier();
             f32x4 v = sum_partials<E>(lds, ia, sa) + *reinterpret_cast<const f32x4*>(ly.b1 + member * C::NC + sa * 4);
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
             store_sc1(FT_RS(A.f_h + tb, blk), frag_off, v);
             if (side_l0) {
-                __syncthreads();
+                wg_barrier();
                 write_partial_side<E>(lds, wave, lane, accs[0]);
-                __syncthreads();
+                wg_barrier();
                 if (sthr) {
                     f32x4 w = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.b1 + member * C::NC + ta * 4);
                     w[0] = fmaxf(w[0], 0.f); w[1] = fmaxf(w[1], 0.f); w[2] = fmaxf(w[2], 0.f); w[3] = fmaxf(w[3], 0.f);
@@ -663,13 +697,14 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
             }
         }
         FT_MARK();
-        team_signal(tctr);
+        team_signal(tctr, member, nsig + 1);
         ++nsig;
-        issue_half<E>(ly.w2, member, wave, lo, 1, slot1);
+        if (wave != 0) issue_half<E>(ly.w2, member, wave, lo, 1, slot1);
         FT_MARK();
 
         // ---- fc2 + residual -------------------------------------------------------------------------------------
-        if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
+        if (!team_wait(tctr, nsig, A.err, s_ok)) return;
+        if (wave == 0) issue_half<E>(ly.w2, member, wave, lo, 1, slot1);
         FT_MARK();                               // team has h
         load_frags<E, C::NA, 5>(FT_RS(A.f_h + tb, blk), wave, lane, a);
         if (side_l0) load_frags<E, C::NS, 4>(FT_RS(A.s_h + tsb, sblk), wave, lane, as);
@@ -681,14 +716,14 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
             gemm_stream<E, 1, 1, 1>(lds, W1, nxt, member, wave, lane, lo, a, acc, side_l0, as, accs);
             FT_MARK();
             write_partial<E>(lds, wave, lane, acc[0]);
-            __syncthreads();
+            wg_barrier();
             const f32x4 v = sum_partials<E>(lds, ia, sa) + *reinterpret_cast<const f32x4*>(ly.b2 + member * C::NC + sa * 4) +
                             R[sa * 32 + ia];
             store_sc1(FT_RS(A.f_z + tb, blk), frag_off, v);
             if (side_l0) {
-                __syncthreads();
+                wg_barrier();
                 write_partial_side<E>(lds, wave, lane, accs[0]);
-                __syncthreads();
+                wg_barrier();
                 if (sthr) {
                     const f32x4 w = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.b2 + member * C::NC + ta * 4) +
                                     RS[ta * FT_SIDE + ja];
@@ -696,15 +731,15 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
                 }
             }
             FT_MARK();
-            team_signal(tctr);
+            team_signal(tctr, member, nsig + 1);
             ++nsig;
-            if (nxt) issue_half<E>(nxt, member, wave, lo, 1, slot1);
+            if (nxt && wave != 0) issue_half<E>(nxt, member, wave, lo, 1, slot1);
             FT_MARK();
         }
     }
 
     // ---- LayerNorm 3 of the last layer: the rows that feed the vocabulary projection -------------------------------
-    if (!team_wait(tctr, FT_TEAM * nsig, A.err, s_ok)) return;
+    if (!team_wait(tctr, nsig, A.err, s_ok)) return;
     FT_MARK();                                   // team has the last layer's z
     load_frags<E, C::NA, 5>(FT_RS(A.f_z + tb, blk), wave, lane, a);
     ln_frags<E, C::NA, 5>(a, A.ly[A.L - 1].n3g, A.ly[A.L - 1].n3b, part, pb, wave, lane);

@@ -1,0 +1,116 @@
+"""All decoder layers of a cached decode step as one launch (csrc/decode_fused.hip; taken by itself at E = 512, H = 4,
+at most two layers, one memory row) against the launch-per-operation form and the oracle (transformer.py:141-175).
+Generated <PAD> tokens are the hard case: the reference lets a <PAD> query row attend uniformly over the CURRENT length,
+which the one-launch form follows by carrying the <PAD> positions along as side rows of their sample's team."""
+import warnings
+
+import pytest
+import torch
+
+from gpu_util import check_greedy, cpu_sd, plain_decoder
+from oracle import decoder_ref as R
+
+pytestmark = pytest.mark.gpu
+
+E, H = 512, 4
+
+
+def _decoder(L, V, seed, pad_bias=0.0, eos_bias=0.0):
+    torch.manual_seed(seed)
+    dec = plain_decoder(E, V, H, L).cuda().eval()
+    with torch.no_grad():
+        dec.fc2.bias[R.PAD] += pad_bias
+        dec.fc2.bias[R.EOS] += eos_bias
+    return dec
+
+
+def _ids(dec, enc, max_len, **kw):
+    from capdec.engine import ids_to_lists, tf_greedy_ids
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")            # a wait of the one-launch form that runs out warns: never expected
+        ids, lengths, n_dirty = tf_greedy_ids(dec, enc.cuda(), max_len, R.SOS, R.EOS, **kw)
+    return ids_to_lists(ids, lengths), n_dirty
+
+
+@pytest.mark.parametrize("L,B", [(2, 1), (2, 33), (2, 100), (1, 40)])
+def test_one_launch_layers_follow_generated_pad_tokens(L, B):
+    V, ML = 2000, 12
+    dec = _decoder(L, V, 40 + L, pad_bias=1.2)
+    g = torch.Generator().manual_seed(B)
+    enc = torch.randn(B, 1, E, generator=g)
+    fused, nd = _ids(dec, enc, ML)
+    # (a team of 32 samples carries up to 16 <PAD> positions; beyond that the surplus samples go to the exact path)
+    pads_per_team = [sum(row.count(R.PAD) for row in fused[i:i + 32]) for i in range(0, B, 32)]
+    print(f"L={L} B={B}: <PAD> positions per team {pads_per_team}, {nd} samples through the exact path")
+    if L == 1 or max(pads_per_team) <= 16:
+        assert nd == 0
+    plain, _ = _ids(dec, enc, ML, fused_layers=False)
+    sd = cpu_sd(dec)
+    ties = check_greedy(fused, sd, enc, H, ML)
+    check_greedy(plain, sd, enc, H, ML)
+    assert sum(a == b for a, b in zip(fused, plain)) >= B - max(1, ties)
+    if B >= 33:
+        # the point of the test: <PAD> in the middle of captions that go on
+        assert sum(R.PAD in row[:-2] for row in fused) >= (2 if B < 64 else 4), [row for row in fused][:4]
+
+
+def test_one_launch_layers_rows_of_the_last_step_and_bit_identical_runs():
+    """The rows handed to the vocabulary projection agree with the launch-per-operation form to rounding, and two runs
+    agree bit for bit (fixed summation orders, no float atomics)."""
+    from capdec.engine import tf_greedy_ids
+    V, B = 3000, 70
+    dec = _decoder(2, V, 7, pad_bias=1.2)
+    g = torch.Generator().manual_seed(5)
+    enc = torch.randn(B, 1, E, generator=g).cuda()
+    for n in (1, 2, 5):
+        wa, wb, wc = [], [], []
+        tf_greedy_ids(dec, enc, n, R.SOS, R.EOS, fused_layers=False, keep_workspace=wa)
+        tf_greedy_ids(dec, enc, n, R.SOS, R.EOS, keep_workspace=wb)
+        tf_greedy_ids(dec, enc, n, R.SOS, R.EOS, keep_workspace=wc)
+        torch.cuda.synchronize()
+        xa, xb, xc = (w[0][:B * E * 4].view(torch.float32).view(B, E).cpu() for w in (wa, wb, wc))
+        assert torch.equal(xb, xc)
+        err = float((xa - xb).abs().max()) / float(xa.abs().max())
+        assert err <= 1e-5, (n, err)
+
+
+def test_one_launch_layers_more_pad_positions_than_side_rows():
+    """More than 16 <PAD> positions among the 32 samples of a team: the surplus samples are flagged and re-decoded on the
+    exact path; the captions are the oracle's either way."""
+    V, B, ML = 500, 64, 10
+    dec = _decoder(2, V, 3, pad_bias=1.5)
+    g = torch.Generator().manual_seed(8)
+    enc = torch.randn(B, 1, E, generator=g)
+    got, n_dirty = _ids(dec, enc, ML)
+    assert n_dirty > 0
+    assert sum(row.count(R.PAD) for row in got[:32]) > 16
+    assert len({tuple(row) for row in got}) > B // 2          # (not a degenerate all-<PAD> batch)
+    check_greedy(got, cpu_sd(dec), enc, H, ML)
+
+
+def test_one_launch_layers_all_captions_finish_and_ragged_batches():
+    """Captions that end: the device-side end of the loop (a row count of zero) reaches the one-launch form too; batch
+    sizes that are no multiple of a team's 32 rows."""
+    V, ML = 1000, 25
+    dec = _decoder(2, V, 11, eos_bias=1.4, pad_bias=0.8)
+    for B in (5, 31, 65):
+        g = torch.Generator().manual_seed(B)
+        enc = torch.randn(B, 1, E, generator=g)
+        got, _ = _ids(dec, enc, ML)
+        plain, _ = _ids(dec, enc, ML, fused_layers=False)
+        ties = check_greedy(got, cpu_sd(dec), enc, H, ML)
+        assert sum(a == b for a, b in zip(got, plain)) >= B - max(1, ties)
+        assert min(len(r) for r in got) < ML
+
+
+def test_one_launch_layers_at_the_benchmark_batch():
+    V, B, ML = 10000, 1024, 20
+    dec = _decoder(2, V, 0)
+    g = torch.Generator().manual_seed(1236)
+    enc = torch.randn(B, 1, E, generator=g)
+    fused, nd = _ids(dec, enc, ML)
+    plain, _ = _ids(dec, enc, ML, fused_layers=False)
+    assert nd == 0
+    same = sum(a == b for a, b in zip(fused, plain))
+    assert same >= B - 4, same
+    check_greedy(fused[:40], cpu_sd(dec), enc[:40], H, ML)
