@@ -165,6 +165,8 @@ def train_bench(device, rank, world, steps, warmup, fence, note=lambda m: None, 
                                    "(ignored by the loss; the decoder stack and the vocabulary projection run on the "
                                    "live rows only)"), "global_batch": world * Bt,
                       "grad_allreduce_bytes": tr.grad_bytes(), "hip_graph": bool(use_graph),
+                      "allreduce_segments": len(tr.segments) if tr.coll else 0,
+                      "allreduces_captured_in_graph": bool(tr.collectives_in_graph),
                       "live_rows_per_step": R, "rows_per_step": Bt * T},
            "algorithmic_tflops": tflops, "mfma_frac": tflops / (world * FP32_MFMA_PEAK_TFLOPS),
            "executed_tflops": tflops_exec, "executed_mfma_frac": tflops_exec / (world * FP32_MFMA_PEAK_TFLOPS),
@@ -495,6 +497,55 @@ def variants_bench(device, steps=6, warmup=2):
     dt = (time.perf_counter() - t0) / steps
     out["decode_grid64"] = {"workload": f"CNN-Attn greedy decode over a 64x2048 feature grid (S=64), B={B}, len {LEN}",
                             "value": B / dt, "unit": "captions/s", "ms_per_step": dt * 1e3}
+    # ---- the headline workload with a step's decoder layers as separate launches (the cross-check of the one-launch
+    #      form that `value` is measured with), and the same decode at the reference's own batch sizes (eval.py:91-102,
+    #      train.py:28) with the oracle's CPU time beside them ----
+    feats_h = torch.rand(B, D, generator=g).to(device)
+
+    def hstep(fused, rows=B):
+        with torch.no_grad():
+            enc = model.encode_features(feats_h[:rows]).view(rows, 1, E)
+            return engine.tf_greedy_ids(model, enc, LEN, 1, 2, to_cpu=True, fused_layers=fused)
+
+    def timed(fn, n=steps):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return r, (time.perf_counter() - t0) / n
+
+    (ids_f, _, _), dt_f = timed(lambda: hstep(True))
+    (ids_u, _, _), dt_u = timed(lambda: hstep(False))
+    out["decode_launch_per_operation"] = {
+        "workload": f"cfg2 CNN-Attn greedy decode, S=1, B={B}, len {LEN}: every operation of a step its own launch",
+        "value": B / dt_u, "unit": "captions/s", "ms_per_step": dt_u * 1e3, "ms_per_step_one_launch_layers": dt_f * 1e3,
+        "rows_with_identical_ids": int((ids_f == ids_u).all(dim=1).sum())}
+    from oracle import decoder_ref as R
+    sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for rows in (32, 64):
+        _, dt_s = timed(lambda: hstep(True, rows), 20)
+        _, dt_su = timed(lambda: hstep(False, rows), 20)
+        with torch.no_grad():
+            enc_cpu, _ = R.head_single(sd_cpu, feats_h[:rows].cpu(), "fc1", training=False)
+            n_cpu, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 2.0:
+                R.greedy_inference_ids(sd_cpu, enc_cpu, H, LEN)
+                n_cpu += 1
+            cpu_dt = (time.perf_counter() - t0) / n_cpu
+        out[f"cfg2_b{rows}"] = {
+            "workload": f"cfg2 CNN-Attn greedy decode, S=1, B={rows} (the reference's own batch sizes), len {LEN}",
+            "value": rows / dt_s, "unit": "captions/s", "ms_per_step": dt_s * 1e3, "ms_per_step_launch_per_operation": dt_su * 1e3,
+            "cpu": {"value": rows / cpu_dt, "unit": "captions/s", "ms_per_step": cpu_dt * 1e3, "cores": torch.get_num_threads(),
+                    "kind": "port", "sample": f"{n_cpu} batches of {rows} in 2 s, oracle restatement of the reference loop"}}
+    del sd_cpu
+    # ---- beam search, width 3 (the other half of every eval.py run: eval.py:128, transformer.py:177-244), KV-cached ----
+    _, dt_b = timed(lambda: model.caption_ids_beam(feats_h, beam_width=3, max_length=LEN), 3)
+    out["beam_w3"] = {"workload": f"cfg2 CNN-Attn beam search, width 3, S=1, B={B}, len {LEN} (KV caches re-gathered by parent)",
+                      "value": B / dt_b, "unit": "captions/s", "ms_per_step": dt_b * 1e3}
+    del feats_h
     # ---- serving-style pipelining of the headline workload: two host threads, each with its own HIP stream, each
     #      running whole B=1024 steps (head + cached greedy decode + ids to the host).  One batch's launch latencies and
     #      small kernels overlap the other's; a step takes longer, the throughput is higher ----
@@ -689,10 +740,13 @@ def main():
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the figure is
         # read from the committed summary of the same command (profiles/vocab_traffic.json: FETCH_SIZE doubled per the
         # gfx950 correction + WRITE_SIZE, KiB -> bytes, averaged per launch); null when the file is absent
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "vocab_traffic.json")) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch") if S == 1 else None
+                tj = json.load(fh)
+            if S == 1:
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/vocab_traffic.json @ {tj.get('set', 'r02_k')} (rocprofv3 --pmc passes of this command, not this run)"
         except (OSError, ValueError):
             traffic = None
         captions = world * B * args.steps
@@ -706,11 +760,13 @@ def main():
             "config": {"workload": f"cfg2 CNN-Attn greedy decode, B={B}/GPU, len {LEN}, E={E}, H={H}, L={L}, V={V}, "
                                    f"memory rows S={S}" + (" (reference-faithful pooled feature)" if S == 1 else
                                                            " (feature-grid variant)"),
-                       "global_batch": world * B, "max_length": LEN, "rows_redecoded_exactly_per_step": dirty_rows / args.steps},
+                       "global_batch": world * B, "max_length": LEN, "rows_redecoded_exactly_per_step": dirty_rows / args.steps,
+                       "step_structure": "3 launches: token pick + embedding, all decoder layers (teams of 8 workgroups per "
+                                         "32 rows), vocabulary projection + arg-max" if S == 1 else "one launch per operation"},
             "roofline": {"bound": "mfma", "kernel": "vocab_reduce_kernel (fc2 projection + fused arg-max)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "avg_launch_ms": avg_ms,
-                         "launches_timed": len(vocab_ms), "traffic": traffic,
+                         "launches_timed": len(vocab_ms), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": 4.0 * (V * E + B * E + V) + 8.0 * B * ((V + 63) // 64)},
         }
 
@@ -726,7 +782,7 @@ def main():
             key = "train_strong" if "train" in out else "train"
             out[key] = {"error": f"training leg did not finish within {args.train_budget} s"}
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)          # the line is out, but the run failed: the caller must see it in the exit code
 
     if args.train_steps > 0:
         watchdog = threading.Timer(args.train_budget, give_up)

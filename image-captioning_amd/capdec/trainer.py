@@ -12,6 +12,7 @@ batch statistics).  Differences in mechanism, not in result:
     of it -- forward, loss, backward, Adam -- can be captured once in a HIP graph and replayed (``graph=True``): one
     host call per step instead of ~150 kernel launches from Python, which is what bounds small per-GPU batches.
 """
+import collections
 import os
 
 import torch
@@ -42,7 +43,7 @@ class CaptionTrainer:
     _SEED_HEAD, _SEED_DECODER = 0x2545F4914F6CDD1D, 0
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, pad_idx=0, overlap=True,
-                 skip_dead_rows=True, wgrad_stream=None, graph=False, exercise_collectives=False):
+                 skip_dead_rows=True, wgrad_stream=None, graph=False, exercise_collectives=False, graph_cache=8):
         """overlap=True: one async all-reduce per gradient segment, issued as soon as the backward pass has enqueued
         that segment; overlap=False: a single all-reduce of the whole flat gradient buffer after the backward pass.
         skip_dead_rows: run the Transformer stack on the live prefix of every caption only (the positions from a
@@ -53,8 +54,14 @@ class CaptionTrainer:
         graph: capture the step in a HIP graph.  The first step with a given input shape runs launch by launch (it
         also lets every kernel variant do its one-time set-up), the second is captured and replayed, later ones are
         replays (inputs are copied into fixed buffers first).  Same kernels in the same order as the launch-by-launch step, hence the
-        same losses and parameters.  With more than one rank the gradient exchange stays outside the graph: forward +
-        backward replay as one graph, then one all-reduce of the flat gradient buffer, then Adam.
+        same losses and parameters.  With more than one rank under RCCL the per-segment all-reduces are captured with the
+        step (each is issued as soon as the backward pass has enqueued its segment, on RCCL's own stream, so it runs
+        beside the rest of the backward pass when the graph replays) and Adam follows the last of them inside the graph;
+        if the capture of a collective is refused, or under gloo (host-staged collectives), the graph holds forward +
+        backward only and one all-reduce of the flat gradient buffer and Adam are launched after the replay.  At most
+        ``graph_cache`` captured shapes are kept (the reference pads every batch to its own longest caption,
+        get_loader.py:184, so the shape changes from batch to batch: pad or bucket the captions to few lengths, or the
+        step mostly runs launch by launch); the least recently used one is dropped.
         exercise_collectives: issue every broadcast / all-reduce even in a one-rank process group (where each is the
         identity), so that the device-collective code path -- asynchronous work handles, segment boundaries, stream
         ordering -- can run on a single GPU under RCCL."""
@@ -65,7 +72,10 @@ class CaptionTrainer:
         self.side_stream = None
         self.betas, self.eps, self.pad_idx = betas, eps, pad_idx
         self.graph = bool(graph)
-        self._graphs = {}              # input shapes -> None (seen once, run eagerly) | captured step
+        self._graphs = collections.OrderedDict()   # input shapes -> None (seen once, run eagerly) | captured step
+        self._graph_cache = max(1, int(graph_cache))
+        self._capture_collectives = True           # until a capture with the all-reduces inside has been refused
+        self.collectives_in_graph = False          # whether the last captured step holds its all-reduces
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         # gloo has no dependable device collectives: stage through the host there (tests and rehearsals on one GPU);
@@ -242,32 +252,50 @@ class CaptionTrainer:
         self._adam()
         return loss
 
+    def _capture(self, cap, inside):
+        """Capture one step into cap.graph.  inside: with the per-segment all-reduces and Adam (device collectives)."""
+        cap.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cap.graph):
+            cap.loss = self._forward_backward(cap.feats, cap.captions, reduce_inside=inside)
+            if inside or not self.coll:
+                self._adam()
+        cap.inside = inside
+
     def _graph_step(self, feats, captions):
         key = (tuple(feats.shape), tuple(captions.shape), feats.dtype, captions.dtype)
         if key not in self._graphs:
             # first sight of this shape: launch by launch (a real step; also every kernel variant's one-time set-up)
             self._graphs[key] = None
-            loss = self._forward_backward(feats, captions, reduce_inside=False)
-            if self.coll:
+            while len(self._graphs) > self._graph_cache:
+                self._graphs.popitem(last=False)           # least recently used shape: its graph and pool are freed
+            loss = self._forward_backward(feats, captions, reduce_inside=self.coll and self.overlap)
+            if self.coll and not self.overlap:
                 self._all_reduce_whole()
             self._adam()
             return loss
+        self._graphs.move_to_end(key)
         cap = self._graphs[key]
         if cap is None:
             cap = Tape()
             cap.feats = torch.empty_like(feats)
             cap.captions = torch.empty_like(captions)
-            cap.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cap.graph):
-                cap.loss = self._forward_backward(cap.feats, cap.captions, reduce_inside=False)
-                if not self.coll:
-                    self._adam()
+            inside = self.coll and not self.host_staged and self.overlap and self._capture_collectives
+            try:
+                self._capture(cap, inside)
+            except RuntimeError:
+                if not inside:
+                    raise
+                # a collective that cannot be captured on this stack: keep the exchange outside the graph from now on
+                self._capture_collectives = False
+                torch.cuda.synchronize()
+                self._capture(cap, False)
+            self.collectives_in_graph = cap.inside
             self._graphs[key] = cap
         cap.feats.copy_(feats)
         cap.captions.copy_(captions)
         cap.graph.replay()
         loss = cap.loss.clone()            # the graph writes the same storage at every replay
-        if self.coll:
+        if self.coll and not cap.inside:
             self._all_reduce_whole()
             self._adam()
         return loss

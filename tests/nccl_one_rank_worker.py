@@ -1,8 +1,11 @@
 """Worker of tests/test_gpu_dist.py::test_rccl_one_rank_group_runs_the_device_collective_branch: a one-rank "nccl"
 (= RCCL) process group on GPU 0.  Four trainers start from the same weights and the same seed and take four steps on
 the same batches: no collectives at all; one asynchronous all-reduce per gradient segment issued during the backward
-pass; one all-reduce of the whole buffer after it; and the step replayed as a HIP graph with the all-reduce between the
-graph and Adam.  In a one-rank group every collective is the identity, so all four must agree.  argv: output .npz."""
+pass; one all-reduce of the whole buffer after it; the step replayed as a HIP graph that holds the per-segment
+all-reduces and Adam; and the graph of forward + backward alone with one all-reduce and Adam launched after each replay.
+In a one-rank group every collective is the identity, so all of them must agree.  The worker also counts the all-reduce
+calls of every step: one per gradient segment while a step is launched or captured, none while it is replayed.
+argv: output .npz."""
 import os
 import sys
 
@@ -29,7 +32,16 @@ def main():
     out = {}
     modes = {"plain": dict(), "segments": dict(exercise_collectives=True, overlap=True),
              "whole": dict(exercise_collectives=True, overlap=False),
-             "graph": dict(exercise_collectives=True, graph=True)}
+             "graph": dict(exercise_collectives=True, graph=True),
+             "graph_outside": dict(exercise_collectives=True, graph=True, overlap=False)}
+    calls = []
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(*a, **k):
+        calls.append(1)
+        return real_all_reduce(*a, **k)
+
+    dist.all_reduce = counting_all_reduce
     for name, kw in modes.items():
         m = VITCNNAttentionModel(64, 90, 4, 2, dropout=0.1)
         m.load_state_dict(sd0)
@@ -37,9 +49,17 @@ def main():
         torch.manual_seed(11)                       # the trainer draws its first dropout seed from this generator
         tr = CaptionTrainer(m, lr=1e-3, **kw)
         assert tr.coll == (name != "plain") and not tr.host_staged and tr.world == 1
-        losses = [float(tr.step(f.to(dev), c.to(dev)).item()) for f, c in batches]
+        losses, per_step = [], []
+        for f, c in batches:
+            del calls[:]
+            losses.append(float(tr.step(f.to(dev), c.to(dev)).item()))
+            per_step.append(len(calls))
         out["loss_" + name] = np.asarray(losses)
+        out["calls_" + name] = np.asarray(per_step)
+        out["nseg_" + name] = np.asarray(len(tr.segments))
+        out["inside_" + name] = np.asarray(int(tr.collectives_in_graph))
         out["p_" + name] = tr.flat_p.detach().cpu().numpy()
+    dist.all_reduce = real_all_reduce
     # the decode side's only exchange: ragged gather of token ids to rank 0
     ids = torch.arange(12, dtype=torch.int64, device=dev).view(3, 4)
     lens = torch.tensor([4, 2, 3], dtype=torch.int32, device=dev)

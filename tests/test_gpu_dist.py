@@ -69,9 +69,11 @@ def test_two_rank_training_matches_ddp_semantics(tmp_path):
 
 def test_rccl_one_rank_group_runs_the_device_collective_branch(tmp_path):
     """The branch that real multi-GPU runs take (RCCL reducing the device buffers in place: asynchronous per-segment
-    all-reduces issued inside the backward pass, the whole-buffer form, and the graph-replayed step with its all-reduce
-    outside the graph) on one GPU, in a one-rank "nccl" group where every collective is the identity: losses and
-    parameters must equal those of the trainer that issues no collective."""
+    all-reduces issued inside the backward pass, the whole-buffer form, the graph-replayed step that holds its
+    per-segment all-reduces and Adam, and the graph of forward + backward with the exchange launched after it) on one GPU,
+    in a one-rank "nccl" group where every collective is the identity: losses and parameters must equal those of the
+    trainer that issues no collective; a launched or captured step issues one all-reduce per gradient segment, a
+    replayed one none from the host."""
     out = str(tmp_path / "one_rank.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_one_rank_worker.py"), out], env=env,
@@ -80,7 +82,14 @@ def test_rccl_one_rank_group_runs_the_device_collective_branch(tmp_path):
     got = np.load(out)
     ref_l, ref_p = got["loss_plain"], got["p_plain"]
     assert ref_l[-1] < ref_l[0] * 1.5 and np.isfinite(ref_p).all()
-    for name in ("segments", "whole", "graph"):
+    nseg = int(got["nseg_graph"])
+    assert got["calls_plain"].tolist() == [0, 0, 0, 0]
+    assert got["calls_segments"].tolist() == [nseg] * 4
+    assert got["calls_whole"].tolist() == [1, 1, 1, 1]
+    assert int(got["inside_graph"]) == 1, "RCCL all-reduces were not captured with the step"
+    assert got["calls_graph"].tolist() == [nseg, nseg, 0, 0]           # launched, captured, replayed, replayed
+    assert int(got["inside_graph_outside"]) == 0 and got["calls_graph_outside"].tolist() == [1, 1, 1, 1]
+    for name in ("segments", "whole", "graph", "graph_outside"):
         assert np.allclose(got["loss_" + name], ref_l, rtol=2e-5, atol=0), (name, got["loss_" + name], ref_l)
         d = np.abs(got["p_" + name] - ref_p)
         # same gradients up to the rounding of the weight gradients' float atomics; Adam turns a sign flip of a
