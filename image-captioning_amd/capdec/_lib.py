@@ -118,6 +118,9 @@ _SIGNATURES = {
                                                 _P, _P, _P, _P, _P]),
     "capdec_layernorm_bwd_rows": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P, _P, _P,
                                           _P]),
+    "capdec_layernorm_bwd_workspace_floats": (c_size_t, [c_int, c_int]),
+    "capdec_layernorm_bwd_staged": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P, _P, _P, _P,
+                                            _P, c_size_t, _P]),
     "capdec_group_sum_segments": (c_int, [_P, c_int, _P, c_int, _P, _P]),
     "capdec_embed_bwd_rows": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "capdec_compact_prefix": (c_int, [_P, _P, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),

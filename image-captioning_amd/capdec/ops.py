@@ -2,6 +2,7 @@
 
 PyTorch is used for device memory and the stream only; all arithmetic happens in libcapdec.so.
 """
+import os
 from ctypes import byref
 
 import torch
@@ -610,9 +611,14 @@ def add_layernorm_train(x, add, gamma, beta, p, seed, eps=1e-5, x_div=1, x_map=N
     return y, s, mean, rstd
 
 
-def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None, rows_dev=None, seed_dev=None):
+_LN_BWD_WS = {}       # (device, floats) -> slab for the two-stage column sums of layernorm_bwd
+LN_BWD_STAGED = os.environ.get("CAPDEC_LN_BWD_STAGED", "1") == "1"
+
+
+def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None, rows_dev=None, seed_dev=None, staged=None):
     """Returns (d_add, d_x); dgamma/dbeta are accumulated, and so are the column sums of d_x into ``dxsum`` [E]
-    when given (the bias gradient of the linear layer whose output was normalised)."""
+    when given (the bias gradient of the linear layer whose output was normalised).  staged: the column sums go
+    through a [workgroups][3E] slab and a second launch instead of float atomics (fixed summation order)."""
     lib = _lib.load()
     M, E = dy.shape
     if not dy.is_contiguous():
@@ -622,11 +628,21 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, p, seed, dgamma, dbeta, dxsum=None, 
     # accumulates further gradients into d_add in place on its main stream while the weight-gradient contraction that
     # reads d_x may still be running on a second stream; one shared tensor would be overwritten under that reader.
     d_x = torch.empty_like(d_add)
-    _lib.check(lib.capdec_layernorm_bwd_rows(_chk(dy).data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                             _chk(gamma).data_ptr(), M, E, p, seed, _seed_ptr(seed_dev), d_add.data_ptr(),
-                                             _ptr(d_x),
-                                             _chk(dgamma).data_ptr(), _chk(dbeta).data_ptr(), _ptr(dxsum),
-                                             _ptr(rows_dev), _stream()), "capdec_layernorm_bwd_rows")
+    ws, nws = None, 0
+    if staged is None:
+        staged = LN_BWD_STAGED
+    if staged and M > 0:
+        nws = int(lib.capdec_layernorm_bwd_workspace_floats(M, E))
+        # one slab per stream: the calls of one stream are ordered, so each may reuse it
+        key = (dy.device, nws, torch.cuda.current_stream(dy.device).cuda_stream)
+        ws = _LN_BWD_WS.get(key)
+        if ws is None:
+            ws = _LN_BWD_WS[key] = torch.empty(nws, device=dy.device, dtype=torch.float32)
+    _lib.check(lib.capdec_layernorm_bwd_staged(_chk(dy).data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               _chk(gamma).data_ptr(), M, E, p, seed, _seed_ptr(seed_dev), d_add.data_ptr(),
+                                               _ptr(d_x),
+                                               _chk(dgamma).data_ptr(), _chk(dbeta).data_ptr(), _ptr(dxsum),
+                                               _ptr(rows_dev), _ptr(ws), nws, _stream()), "capdec_layernorm_bwd_staged")
     return d_add, d_x
 
 

@@ -145,6 +145,11 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
 // Rows per workgroup (LNB_ROWS, a launch argument): 32 (8 per wavefront) for batches of thousands of rows (16 and 64 both
 // measured slower there); fewer, down to 8, when that would leave most of the chip without a workgroup.
 
+// The column sums (dgamma, dbeta, the bias gradient dxsum) of a workgroup's rows meet in 3*E floats of LDS (LDS atomic
+// adds: 6 KiB at E = 512, so that the kernel finds room on a CU beside the 72 KiB tiles of a weight-gradient contraction
+// running on the second stream).  From there they go to memory either as one float atomic per column and workgroup, or
+// (`partials` given) as this workgroup's row of a [workgroups][3*E] slab that ln_bwd_reduce_kernel sums afterwards:
+// 320 workgroups x 1536 columns of same-address atomics are a 16 us tail (about 50 ns each), the slab is not.
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -153,12 +158,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      float* __restrict__ d_add, float* __restrict__ d_x,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      float* __restrict__ dxsum, const int32_t* __restrict__ rows_dev,
-                                                     int LNB_ROWS) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][3][E]
+                                                     int LNB_ROWS, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [3][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (rows_dev) M = min(M, rows_dev[0]);
     if (seed_dev) seed += seed_dev[0];
-    if ((int)blockIdx.x * LNB_ROWS >= M) return;
+    float* prow = partials ? partials + (int64_t)blockIdx.x * 3 * E : nullptr;
+    if ((int)blockIdx.x * LNB_ROWS >= M) {
+        if (prow)                                   // no live row here: the reduction still reads this row of the slab
+            for (int c = threadIdx.x; c < 3 * E; c += 256) prow[c] = 0.f;
+        return;
+    }
+    for (int c = threadIdx.x; c < 3 * E; c += 256) lds[c] = 0.f;
+    __syncthreads();
     const int nv = E / 4;
     const float inv_keep = 1.0f / (1.0f - p);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
@@ -213,31 +225,66 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     }
-    // combine the 4 wavefronts' column partials, then one atomic per column and workgroup
-    float* pg = lds + (wave * 3 + 0) * E;
-    float* pb = lds + (wave * 3 + 1) * E;
-    float* px = lds + (wave * 3 + 2) * E;
+    // the 4 wavefronts' column partials meet in LDS (wavefront after wavefront in a fixed order: the sums, and with the
+    // slab the gradients, are the same from run to run)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int u = 0; u < NV; ++u) {
-        const int c = lane + 64 * u;
-        if (c < nv) {
-            reinterpret_cast<f32x4*>(pg)[c] = ag[u];
-            reinterpret_cast<f32x4*>(pb)[c] = ab[u];
-            reinterpret_cast<f32x4*>(px)[c] = ax[u];
+            for (int u = 0; u < NV; ++u) {
+                const int c = lane + 64 * u;
+                if (c < nv) {
+                    f32x4* a0 = reinterpret_cast<f32x4*>(lds) + c;
+                    a0[0] += ag[u];
+                    a0[nv] += ab[u];
+                    a0[2 * nv] += ax[u];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (prow) {
+        for (int c = threadIdx.x; c < 3 * nv; c += 256) reinterpret_cast<f32x4*>(prow)[c] = reinterpret_cast<const f32x4*>(lds)[c];
+        return;
+    }
+    for (int c = threadIdx.x; c < E; c += 256) {
+        atomicAdd(&dgamma[c], lds[c]);
+        atomicAdd(&dbeta[c], lds[E + c]);
+        if (dxsum) atomicAdd(&dxsum[c], lds[2 * E + c]);
+    }
+}
+
+// Second stage: out_k[c] += sum over the nwg rows of the slab, k = 0, 1, 2 for dgamma, dbeta, dxsum (nullable).  A
+// workgroup owns 64 columns (16 lanes x 16 B) of one of the three and its 16 row groups walk the slab rows, eight in
+// flight per thread, in a fixed order.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partials, int nwg, int E,
+                                                            float* __restrict__ o0, float* __restrict__ o1,
+                                                            float* __restrict__ o2) {
+    __shared__ f32x4 red[16][16];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int strips = (E + 63) / 64;
+    const int k = blockIdx.x / strips, j = (blockIdx.x - k * strips) * 64 + cl * 4;
+    float* out = k == 0 ? o0 : (k == 1 ? o1 : o2);
+    if (!out) return;
+    f32x4 acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (j < E) {
+        for (int r = rg; r < nwg; r += 128) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rr = r + 16 * u;
+                if (rr < nwg) acc[u] += *reinterpret_cast<const f32x4*>(partials + ((int64_t)rr * 3 + k) * E + j);
+            }
         }
     }
+    red[rg][cl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
-    for (int c = threadIdx.x; c < E; c += 256) {
-        float sg = 0.f, sb = 0.f, sx = 0.f;
+    if (rg == 0 && j < E) {
+        f32x4 t = red[0][cl];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            sg += lds[(w * 3 + 0) * E + c];
-            sb += lds[(w * 3 + 1) * E + c];
-            sx += lds[(w * 3 + 2) * E + c];
-        }
-        atomicAdd(&dgamma[c], sg);
-        atomicAdd(&dbeta[c], sb);
-        if (dxsum) atomicAdd(&dxsum[c], sx);
+        for (int g = 1; g < 16; ++g) t += red[g][cl];
+        f32x4* o = reinterpret_cast<f32x4*>(out + j);
+        *o = *o + t;
     }
 }
 
@@ -1508,27 +1555,53 @@ int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, con
                                      nullptr, stream);
 }
 
+static int ln_bwd_rows_per_block(int M) {
+    const int per = (M + 255) / 256;
+    return M >= 8192 ? 32 : (per < 8 ? 8 : (per > 32 ? 32 : (per + 3) / 4 * 4));
+}
+
+size_t capdec_layernorm_bwd_workspace_floats(int M, int E) {
+    if (M <= 0 || E < 4) return 0;
+    const int per = ln_bwd_rows_per_block(M);
+    return (size_t)((M + per - 1) / per) * 3 * (size_t)E;
+}
+
 int capdec_layernorm_bwd_rows(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                               int M, int E, float p, uint64_t seed, const uint64_t* seed_dev, float* d_add, float* d_x,
                               float* dgamma, float* dbeta, float* dxsum, const int32_t* rows_dev, void* stream) {
+    return capdec_layernorm_bwd_staged(dy, s, mean, rstd, gamma, M, E, p, seed, seed_dev, d_add, d_x, dgamma, dbeta, dxsum,
+                                       rows_dev, nullptr, 0, stream);
+}
+
+int capdec_layernorm_bwd_staged(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
+                                int M, int E, float p, uint64_t seed, const uint64_t* seed_dev, float* d_add, float* d_x,
+                                float* dgamma, float* dbeta, float* dxsum, const int32_t* rows_dev, float* workspace,
+                                size_t workspace_floats, void* stream) {
     CAPDEC_REQUIRE(dy && s && mean && rstd && gamma && dgamma && dbeta && M >= 0 && E >= 4 && E % 4 == 0 &&
                    E <= 256 * LN_MAXV && p >= 0.f && p < 1.f);
     if (!capdec_aligned16(dy) || !capdec_aligned16(s) || !capdec_aligned16(gamma) || (d_add && !capdec_aligned16(d_add)) ||
         (d_x && !capdec_aligned16(d_x)))
         return CAPDEC_EALIGN;
     if (M == 0) return 0;
-    // rows wider than 1365 floats need more than the default 64 KiB of dynamic LDS (only the widest instantiation)
-    static const bool wide_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<8>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 2048 * 4) == hipSuccess;
-    if (!wide_ok) return CAPDEC_EINVAL;
-    int per = (M + 255) / 256;
-    per = M >= 8192 ? 32 : (per < 8 ? 8 : (per > 32 ? 32 : (per + 3) / 4 * 4));
+    const int per = ln_bwd_rows_per_block(M);
+    const int nwg = (M + per - 1) / per;
+    if (workspace) {
+        if (workspace_floats < (size_t)nwg * 3 * E) return CAPDEC_ENOMEM;
+        if (!capdec_aligned16(workspace) || !capdec_aligned16(dgamma) || !capdec_aligned16(dbeta) ||
+            (dxsum && !capdec_aligned16(dxsum)))
+            return CAPDEC_EALIGN;
+    }
 #define CAPDEC_CALL(NV_)                                                                                           \
-    hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3((M + per - 1) / per), dim3(256), 12 * E * sizeof(float),           \
-                       (hipStream_t)stream, dy, s, mean, rstd, gamma, M, E, p, seed, seed_dev, d_add, d_x, dgamma, dbeta, dxsum, rows_dev, per)
+    hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3(nwg), dim3(256), 3 * E * sizeof(float), (hipStream_t)stream, dy, s, mean, \
+                       rstd, gamma, M, E, p, seed, seed_dev, d_add, d_x, dgamma, dbeta, dxsum, rows_dev, per, workspace)
     CAPDEC_LN_DISPATCH(E, CAPDEC_CALL);
 #undef CAPDEC_CALL
     CAPDEC_LAUNCH_CHECK();
+    if (workspace) {
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(3 * ((E + 63) / 64)), dim3(256), 0, (hipStream_t)stream, workspace, nwg,
+                           E, dgamma, dbeta, dxsum);
+        CAPDEC_LAUNCH_CHECK();
+    }
     return 0;
 }
 

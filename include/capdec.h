@@ -298,6 +298,15 @@ int capdec_layernorm_bwd(const float* dy, const float* s, const float* mean, con
 int capdec_layernorm_bwd_rows(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                               int M, int E, float p, uint64_t seed, const uint64_t* seed_dev, float* d_add, float* d_x,
                               float* dgamma, float* dbeta, float* dxsum, const int32_t* rows_dev, void* stream);
+/* The same with the three column sums taken in two stages (autograd of nn.LayerNorm, transformer.py:85,87,89): every
+ * workgroup stores its sums as one row of `workspace` ([workgroups][3*E] floats, capdec_layernorm_bwd_workspace_floats(M, E)
+ * of them; nullable: then one float atomic per column and workgroup as above) and a second launch adds the rows to
+ * dgamma / dbeta / dxsum in a fixed order.  CAPDEC_ENOMEM if the workspace is too small. */
+size_t capdec_layernorm_bwd_workspace_floats(int M, int E);
+int capdec_layernorm_bwd_staged(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
+                                int M, int E, float p, uint64_t seed, const uint64_t* seed_dev, float* d_add, float* d_x,
+                                float* dgamma, float* dbeta, float* dxsum, const int32_t* rows_dev, float* workspace,
+                                size_t workspace_floats, void* stream);
 /* out[j] += sum_i x[i*ldx + j] */
 int capdec_colsum(const float* x, int64_t ldx, int M, int N, float* out, void* stream);
 /* The same over the first min(M, rows_dev[0]) rows (rows_dev: nullable device scalar). */

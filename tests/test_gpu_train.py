@@ -465,6 +465,51 @@ def test_dropout_statistics_and_mask_replay():
     close(d_x, ops.dropout(d_add, 0.1, 777), rtol=1e-6)
 
 
+@pytest.mark.parametrize("M,E", [(1, 64), (37, 256), (1000, 512), (10240, 512), (700, 1024)])
+def test_layernorm_backward_two_stage_column_sums(M, E):
+    """The LayerNorm backward kernel hands dgamma / dbeta / the bias-gradient column sums to a second launch through a
+    per-workgroup slab: against fp64 arithmetic (autograd of nn.LayerNorm, transformer.py:85,87,89), against the form
+    with float atomics, accumulating into what the outputs already hold, bit-identical from run to run, and with a
+    device-side row count."""
+    from capdec import ops
+    g = torch.Generator().manual_seed(M + E)
+    s = torch.randn(M, E, generator=g).cuda()
+    dy = torch.randn(M, E, generator=g).cuda()
+    gam = (1 + 0.1 * torch.randn(E, generator=g)).cuda()
+    zero = torch.zeros(E, device="cuda")
+    _, _, mean, rstd = ops.add_layernorm_train(s, torch.zeros_like(s), gam, zero, 0.0, 1)
+    base = torch.randn(3, E, generator=g).cuda()
+
+    def run(staged, rows_dev=None):
+        out = base.clone()
+        d_add, d_x = ops.layernorm_bwd(dy, s, mean, rstd, gam, 0.0, 1, out[0], out[1], dxsum=out[2], staged=staged,
+                                       rows_dev=rows_dev)
+        return d_add, d_x, out
+
+    d_add, d_x, out = run(True)
+    d_add2, _, out2 = run(False)
+    assert torch.equal(d_add, d_add2) and torch.equal(d_add, d_x)
+    s64, dy64, g64 = s.double().cpu(), dy.double().cpu(), gam.double().cpu()
+    mu = s64.mean(1, keepdim=True)
+    rs = 1.0 / torch.sqrt(s64.var(1, unbiased=False, keepdim=True) + 1e-5)
+    xh = (s64 - mu) * rs
+    gg = dy64 * g64
+    want = rs * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True))
+    close(d_add, want, rtol=2e-5, what="d_add")
+    cols = torch.stack([(dy64 * xh).sum(0), dy64.sum(0), want.sum(0)]) + base.double().cpu()
+    for k, name in enumerate(("dgamma", "dbeta", "dxsum")):
+        close(out[k], cols[k], rtol=2e-5, what=name + " (slab)")
+        close(out2[k], cols[k], rtol=2e-5, what=name + " (atomics)")
+    assert torch.equal(run(True)[2], out)
+    if M >= 37:
+        live = M - M // 3
+        rows_dev = torch.tensor([live], dtype=torch.int32, device="cuda")
+        _, _, out3 = run(True, rows_dev)
+        cols3 = torch.stack([(dy64 * xh)[:live].sum(0), dy64[:live].sum(0), want[:live].sum(0)]) + base.double().cpu()
+        for k in range(3):
+            close(out3[k], cols3[k], rtol=2e-5, what=f"column sums {k} over the live rows")
+
+
 def test_train_mode_with_dropout_runs_and_is_seeded():
     fx = load_golden("f4_decoder_forward")
     dec = decoder_from_sd(sub_sd(fx, "sd__"), int(fx["H"]), dropout=0.1).train()
