@@ -1107,7 +1107,8 @@ int launch_gemm_cfg(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, hip
 }
 
 // Tile choice.  cfg = 0: automatic; otherwise force: 11 / 116 = 64x64 (BK 32 / 16), 22 / 216 = 128x128 (BK 32 / 16),
-// 32 / 316 = 32x64 tile with the k-loop split over the workgroup's two wave pairs (BK 32 / 16).
+// 32 / 316 = 32x64 tile with the k-loop split over the workgroup's two wave pairs (BK 32 / 16), 2132 / 2116 = 128x64
+// (64x32 per wavefront; BK 32 / 16).
 CAPDEC_HOOK_VAR(g_force_cfg);
 
 template <bool TP, bool TQ>
@@ -1133,8 +1134,14 @@ int launch_gemm_layout(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, 
         // slabs in a workspace sized by splitk_plan) keeps the rule its workspace was sized for.
         if (atomic && a.x.splitk_ws) cfg = tiles64 >= 1024 ? 216 : 11;
         else if (atomic) cfg = (tiles64 >= 1024 && a.K >= 8192) ? 216 : 316;
-        else cfg = tiles64 <= 160 ? 32 : (tiles64 < 512 ? 316 : (tiles64 < 1024 ? 11 : 116));
+        // (512 ... 1023 tiles, 512-deep, 7488 rows: forward 44.4 us on 128x64 tiles at BK 32 against 47.7 on 64x64 ones,
+        //  input gradient 44.6 us on 64x64 tiles at BK 16 against 45.5 at BK 32; at 10240 rows the 64x64 tiles stay:
+        //  tools/exp/tile_probe.py.  Giving a wavefront 64x32 instead of 32x32 does not lift the 53-56 % of the MFMA peak
+        //  these 512-deep launches reach: their LDS reads are not what holds them.)
+        else cfg = tiles64 <= 160 ? 32 : (tiles64 < 512 ? 316 : (tiles64 < 1024 ? (TQ ? 116 : 2132) : 116));
     }
+    if (cfg == 2116) return launch_gemm_cfg<2, 2, 1, 16, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
+    if (cfg == 2132) return launch_gemm_cfg<2, 2, 1, 32, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
     if (cfg == 22) return launch_gemm_cfg<2, 2, 2, 32, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
     if (cfg == 216) return launch_gemm_cfg<2, 2, 2, 16, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
     if (cfg == 32) return launch_gemm_cfg<1, 1, 1, 32, TP, TQ, 2>(a, ngroups, maxI, maxJ, vec, s);
@@ -1217,7 +1224,8 @@ extern "C" {
 
 #ifdef CAPDEC_TUNING_HOOKS
 int capdec_gemm_force_config(int cfg) {
-    CAPDEC_REQUIRE(cfg == 0 || cfg == 11 || cfg == 22 || cfg == 216 || cfg == 32 || cfg == 116 || cfg == 316);
+    CAPDEC_REQUIRE(cfg == 0 || cfg == 11 || cfg == 22 || cfg == 216 || cfg == 32 || cfg == 116 || cfg == 316 || cfg == 2116 ||
+                   cfg == 2132);
     g_force_cfg = cfg;
     return 0;
 }
