@@ -124,9 +124,13 @@ struct capdec_fused_args {
     const int32_t* tok; int64_t ldtok;
     const int32_t* nrows;     // device scalar: 0 once every caption has finished
     const int32_t* done;      // [B]
-    const int32_t* pcount;    // [teams] <PAD> positions recorded for the team's samples (beyond 16: flagged for the exact path)
-    const int32_t* plist;     // [teams][16] sample * max_len + position
+    const int32_t* plist;     // [teams][16] sample * max_len + position of a generated <PAD>, -1: free slot
     const float *emb, *pe;
+    // step t >= 1 also picks the tokens of step t-1 (pval != NULL): per-tile arg-max winners of the previous vocabulary
+    // projection in, the reference's bookkeeping out (what cached_advance_kernel does as a launch of its own otherwise)
+    const float* pval; const int32_t* pidx; int ntiles, V, eos;
+    int32_t *tok_w, *done_w, *out_len, *dirty, *fin, *nrows_w, *pcount_w, *plist_w;
+    int64_t* out_ids;
     unsigned* ctr;            // [teams][32] arrival counters of this step (one per 128-byte line), zero before the launch
     unsigned* err;            // raised by a workgroup whose bounded wait ran out
     unsigned long long* trace;   // probe builds only (CAPDEC_FUSED_TRACE): [8][64] stage timestamps of team trace_team

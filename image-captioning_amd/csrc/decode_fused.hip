@@ -32,6 +32,10 @@
 // layer-1 key and value, written to the cache before the team's layer-1 attention reads them.  With one layer nothing
 // has to be re-run at all.  A team whose samples hold more than 16 <PAD> positions flags the surplus samples for the
 // exact path (out_dirty).
+// The launch of step t >= 1 also finishes step t-1: every member merges the per-tile arg-max winners of the previous
+// vocabulary projection for its team's 32 rows (the token ids it needs for the embedding rows anyway), member 0 does the
+// reference's bookkeeping for them (transformer.py:155-171), and the input rows are built in registers: no separate
+// token-pick launch, no round trip of the input rows through memory.
 // Progress: a team only ever waits for its own members; workgroups are dispatched in index order, so the members of the
 // oldest unfinished team are resident or next in line.  Every wait is a bounded spin: a workgroup that gives up raises
 // `err` and returns, and the caller re-decodes the batch on the exact path.
@@ -74,7 +78,7 @@ struct FT {
     static constexpr int OFF_PART = OFF_CST + 16 * CST_LD;      // [2][8][32] LayerNorm partial sums
     static constexpr int OFF_SC = OFF_PART + 2 * FT_WAVES * 32; // [8][2][64] probability rows (two (row, head) pairs per wavefront)
     static constexpr int OFF_META = OFF_SC + FT_WAVES * 128;    // ints: row descriptors, wait flag
-    static constexpr int LDS_FLOATS = OFF_META + 2 * 32 + 4 * 16 + 16;
+    static constexpr int LDS_FLOATS = OFF_META + 4 * 32 + 4 * 16 + 16;
     static_assert(NH == 2 && NT >= 1 && KW == NC && NC == 64, "team kernel built for E = 512");
 };
 
@@ -364,7 +368,23 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
     const int xg = blockIdx.x & 7, gslot = blockIdx.x >> 3;
     const int team = (gslot >> 3) * 8 + xg, member = gslot & 7;
     if (team >= A.teams) return;
-    if (A.nrows[0] <= 0) return;                            // every caption has finished
+    const int pos_new = A.Tk - 1;
+    const bool pick = A.pval != nullptr && pos_new >= 1;     // this launch also picks the previous step's tokens
+    if (pick) {
+        // The reference leaves its loop once every caption holds an <EOS> (transformer.py:166-168): fin[s] counts the
+        // captions that finished at step s; the counts of the steps before the previous one are final (no workgroup of
+        // this launch changes them), so every workgroup decides alike.  Nothing is recorded then, and the vocabulary
+        // projection of this step finds a row count of zero.
+        int fin_before = 0;
+        for (int q = lane; q < pos_new - 1; q += 64) fin_before += A.fin[q];
+        fin_before = (int)wave_sum((float)fin_before);
+        if (fin_before >= A.B) {
+            if (blockIdx.x == 0 && tid == 0) A.nrows_w[0] = 0;
+            return;
+        }
+    } else if (A.nrows[0] <= 0) {
+        return;                                             // every caption has finished
+    }
 
     float* slot0 = lds + C::OFF_W0;
     float* slot1 = lds + C::OFF_W1;
@@ -376,24 +396,85 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
     int *s_b = meta, *s_flags = meta + 32;                  // main rows: sample (clamped), bit 0 live, bit 1 <PAD> query
     int *ss_map = meta + 64, *ss_b = meta + 80, *ss_pos = meta + 96, *ss_act = meta + 112;   // side rows
     int* s_ok = meta + 128;
-    const int pos_new = A.Tk - 1;
+    int *s_tokn = meta + 144, *s_done = meta + 176;         // newest token and finished flag of the main rows
+    if (pick) {
+        // the arg-max of the previous step's vocabulary projection (per-tile winners merged, lowest index on ties), as
+        // cached_advance_kernel does: four rows per wavefront, every member for all 32 rows of its team
+        // (the loads of the four rows are all issued before the first merge: one round trip, not four)
+        float pv[4][3];
+        int pi[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = min(team * FT_ROWS + wave * 4 + q, A.B - 1);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int n = lane + 64 * u;
+                const int64_t off = capdec_part_off(b, n < A.ntiles ? n : 0, A.ntiles);
+                pv[q][u] = A.pval[off];
+                pi[q][u] = A.pidx[off];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave * 4 + q;
+            const int b = min(team * FT_ROWS + row, A.B - 1);
+            float v = -INFINITY;
+            int i = INT_MAX;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (lane + 64 * u < A.ntiles) argmax_merge(v, i, pv[q][u], pi[q][u]);
+            for (int n = lane + 192; n < A.ntiles; n += 64)          // vocabularies beyond 192 tiles of 64 ids
+                argmax_merge(v, i, A.pval[capdec_part_off(b, n, A.ntiles)], A.pidx[capdec_part_off(b, n, A.ntiles)]);
+            wave_argmax(v, i);
+            if (i < 0 || i >= A.V) i = 0;                   // all-NaN row: no finite winner
+            if (lane == 0) {
+                s_tokn[row] = i;
+                s_done[row] = (A.done_w[b] != 0 || i == A.eos) ? 1 : 0;   // (member 0 may be setting the flag: either way 1)
+            }
+        }
+        wg_barrier();
+        if (member == 0 && tid < FT_ROWS && team * FT_ROWS + tid < A.B) {
+            // the reference's bookkeeping of the token (transformer.py:155-171): a finished row records nothing
+            const int b = team * FT_ROWS + tid, i = s_tokn[tid];
+            A.tok_w[(int64_t)b * A.ldtok + pos_new] = i;
+            if (!A.done_w[b]) {
+                if (i == A.eos) {
+                    A.done_w[b] = 1;
+                    atomicAdd(&A.fin[pos_new - 1], 1);
+                } else {
+                    const int n = A.out_len[b];
+                    A.out_ids[(int64_t)b * A.max_len + n] = i;
+                    A.out_len[b] = n + 1;
+                    if (i == 0 && A.L >= 2) {
+                        // a <PAD> position: a side row of this team from the next step on
+                        const int slot = atomicAdd(&A.pcount_w[team], 1);
+                        if (slot < FT_SIDE) A.plist_w[team * FT_SIDE + slot] = b * A.max_len + pos_new;
+                        else if (A.dirty[b] == 0) A.dirty[b] = 1;
+                    }
+                }
+            }
+        }
+    }
     if (tid < FT_ROWS) {
         const int b0 = team * FT_ROWS + tid;
         const bool act = b0 < A.B;
         const int b = act ? b0 : team * FT_ROWS;
-        const int pad = A.tok[(int64_t)b * A.ldtok + pos_new] == 0;
+        const int pad = (pick ? s_tokn[tid] : A.tok[(int64_t)b * A.ldtok + pos_new]) == 0;
         s_b[tid] = b;
         s_flags[tid] = (act ? 1 : 0) | (pad << 1);
+        if (!pick) s_done[tid] = 0;
     } else if (tid < FT_ROWS + FT_SIDE) {
-        // <PAD> positions of the team's samples before the newest one, still decoding
+        // <PAD> positions of the team's samples before the newest one, still decoding.  (List slots start at -1 and are
+        // written once, by one 4-byte store: a reader sees -1 or the entry, whatever the writer of this launch does.)
         const int sr = tid - FT_ROWS;
-        const int n = A.L >= 2 ? min(A.pcount[team], FT_SIDE) : 0;
-        const int m = sr < n ? A.plist[team * FT_SIDE + sr] : team * FT_ROWS * A.max_len;
+        const int m0 = A.L >= 2 ? A.plist[team * FT_SIDE + sr] : -1;
+        const int m = m0 >= 0 ? m0 : team * FT_ROWS * A.max_len;
         const int b = m / A.max_len, pos = m - b * A.max_len;
         ss_map[sr] = m;
         ss_b[sr] = b;
         ss_pos[sr] = pos;
-        ss_act[sr] = (sr < n && pos < pos_new && !A.done[b]) ? 1 : 0;
+        const int fin_row = pick ? s_done[b - team * FT_ROWS] : A.done[b];
+        ss_act[sr] = (m0 >= 0 && pos < pos_new && !fin_row) ? 1 : 0;
     }
     wg_barrier();
     bool side = false;
@@ -426,7 +507,14 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
         const bool side_kv = side && l == 1;     // the side rows' layer-1 keys and values
 
         // ---- q, k, v projections of the layer input ---------------------------------------------------------
-        if (l == 0) {
+        if (l == 0 && pick) {
+            // the input row of the newest position: embedding of the token just picked + its position (transformer.py:126)
+            const float* er = A.emb + (int64_t)s_tokn[r] * E + wave * C::KW + 4 * h;
+            const float* pr = A.pe + (int64_t)pos_new * E + wave * C::KW + 4 * h;
+#pragma unroll
+            for (int kc = 0; kc < C::NA; ++kc)
+                a[kc] = *reinterpret_cast<const f32x4*>(er + kc * 8) + *reinterpret_cast<const f32x4*>(pr + kc * 8);
+        } else if (l == 0) {
             const float* xr = A.x + (int64_t)s_b[r] * E + wave * C::KW + 4 * h;
 #pragma unroll
             for (int kc = 0; kc < C::NA; ++kc) a[kc] = *reinterpret_cast<const f32x4*>(xr + kc * 8);

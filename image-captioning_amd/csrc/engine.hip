@@ -821,7 +821,7 @@ static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, 
 
 __global__ void cached_init_kernel(int32_t* tok, int64_t ldtok, int32_t* done, int32_t* first_pad, int64_t* out_ids,
                                    int32_t* out_len, int32_t* dirty, int32_t* rowmap, int32_t* nrows,
-                                   int32_t* fin, int B, int max_len, int sos, int32_t* pcount, int nteams) {
+                                   int32_t* fin, int B, int max_len, int sos, int32_t* pcount, int32_t* plist, int nteams) {
     const int n = B * max_len;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     for (int idx = tid; idx < n; idx += nth) out_ids[idx] = -1;
@@ -835,8 +835,10 @@ __global__ void cached_init_kernel(int32_t* tok, int64_t ldtok, int32_t* done, i
     }
     for (int t = tid; t <= max_len; t += nth) nrows[t] = B;
     for (int t = tid; t < max_len; t += nth) fin[t] = 0;
-    if (pcount)
+    if (pcount) {
         for (int t = tid; t < nteams; t += nth) pcount[t] = 0;
+        for (int t = tid; t < nteams * CAPDEC_FUSED_SIDE_ROWS; t += nth) plist[t] = -1;      // free slots of the <PAD> lists
+    }
 }
 
 // One wavefront per sample: pick the token (as greedy_advance_kernel), then prepare step t+1: the sample's new row and,
@@ -859,6 +861,7 @@ __global__ __launch_bounds__(256) void cached_advance_kernel(const float* __rest
                                                              int32_t* pcount, int32_t* plist, const unsigned* fuse_err) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (fuse_err && fuse_err[0] && dirty && b < B && lane == 0) dirty[b] = 2;   // a wait of the one-launch layers ran out: redo the sample exactly
     int fin_before = 0;
     for (int s = lane; s < t; s += 64) fin_before += fin[s];
 #pragma unroll
@@ -899,7 +902,6 @@ __global__ __launch_bounds__(256) void cached_advance_kernel(const float* __rest
         }
         p0 = first_pad[b];
         running = !done[b];          // a finished row's later tokens are discarded: no need to keep it exact
-        if (fuse_err && fuse_err[0] && dirty) dirty[b] = 2;      // a wait of the one-launch layers ran out: redo the sample exactly
         if (x_next) {
             rowmap_next[b] = b * max_len + t + 1;
             if (!pcount && p0 != INT_MAX && running && t + 1 > p0) base = atomicAdd(nrows_next, t + 1 - p0) - B;
@@ -1002,7 +1004,7 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
     CAPDEC_REQUIRE(!(flags & CAPDEC_DECODE_FOLD_MEMORY) || fold);      // forced but unavailable (S < 3 or E not built)
 
     hipLaunchKernelGGL(cached_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, w.first_pad, out_ids,
-                       out_len, out_dirty, w.rowmap, w.nrows, w.fin, B, max_len, sos, w.pcount, w.fused_teams);
+                       out_len, out_dirty, w.rowmap, w.nrows, w.fin, B, max_len, sos, w.pcount, w.plist, w.fused_teams);
     CAPDEC_LAUNCH_CHECK();
     CAPDEC_TRY(capdec_embed_pe(w.tok, 1, ldtok, m->emb, m->pe, 0, B, 1, E, V, w.x, stream));
     // all layers of a step in one launch (single memory row, supported shape): the arrival counters of every step start at zero
@@ -1050,7 +1052,13 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
             fa.x = w.x; fa.q = w.tq; fa.f_ctx = w.tctx; fa.f_y = w.ty; fa.f_h = w.th; fa.f_z = w.tz;
             fa.s_ctx = w.sctx; fa.s_y = w.sy; fa.s_h = w.sh; fa.s_z = w.sz;
             fa.tok = w.tok; fa.ldtok = ldtok; fa.nrows = rows; fa.done = w.done;
-            fa.pcount = w.pcount; fa.plist = w.plist; fa.emb = m->emb; fa.pe = m->pe;
+            fa.plist = w.plist; fa.emb = m->emb; fa.pe = m->pe;
+            if (t >= 1) {
+                // this launch also picks the tokens of step t-1 (no token-pick launch between the steps)
+                fa.pval = w.pval; fa.pidx = w.pidx; fa.ntiles = nt; fa.V = V; fa.eos = eos;
+                fa.tok_w = w.tok; fa.done_w = w.done; fa.out_ids = out_ids; fa.out_len = out_len; fa.dirty = out_dirty;
+                fa.fin = w.fin; fa.nrows_w = w.nrows + t; fa.pcount_w = w.pcount; fa.plist_w = w.plist;
+            }
             fa.ctr = w.ctr + (size_t)t * ctr_step; fa.err = fuse_err;
             CAPDEC_TRY(capdec_launch_fused_layers(fa, E, s));
         }
@@ -1114,6 +1122,7 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
         CAPDEC_TRY(capdec_launch_vocab_argmax_rows(w.x, E, m->fc2_w, m->fc2_b, B, V, E, w.pval, w.pidx, rows, s));
         if (probed) CAPDEC_TRY((int)hipEventRecord((hipEvent_t)probe->end[t], s));
         const bool last = (t + 1 == max_len);
+        if (fused && !last) continue;              // the next step's launch picks this step's tokens
         hipLaunchKernelGGL(cached_advance_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pval, w.pidx, B, nt, t, max_len,
                            eos, w.tok, ldtok, w.done, w.first_pad, out_ids, out_len, out_dirty, m->emb, m->pe, E, V,
                            last ? nullptr : w.x, last ? nullptr : w.rowmap + (size_t)(t + 1) * Mcap,

@@ -57,22 +57,20 @@ int main(int argc, char** argv) {
     a.f_h = dev_random(TE, 1.f, g); a.f_z = dev_random(TE, 1.f, g);
     a.s_ctx = dev_random(SE, 1.f, g); a.s_y = dev_random(SE, 1.f, g); a.s_h = dev_random(SE, 1.f, g); a.s_z = dev_random(SE, 1.f, g);
     a.emb = dev_random((size_t)16 * E, 1.f, g); a.pe = dev_random((size_t)max_len * E, 1.f, g);
-    std::vector<int32_t> tok((size_t)B * (max_len + 1), 5), nrows(1, B), done(B, 0), pcount(nteams, 0), plist((size_t)nteams * 16, 0);
+    std::vector<int32_t> tok((size_t)B * (max_len + 1), 5), nrows(1, B), done(B, 0), plist((size_t)nteams * 16, -1);
     for (int t = 0; t < nteams; t += 4) {
-        pcount[t] = npad;
         for (int k = 0; k < npad && k < 16; ++k) {
             const int b = t * 32 + (k % 32), pos = k % (Tk > 1 ? Tk - 1 : 1);
             plist[t * 16 + k] = b * max_len + pos;
             tok[(size_t)b * (max_len + 1) + pos] = 0;
         }
     }
-    int32_t *dtok, *dn, *ddone, *dpc, *dpl;
+    int32_t *dtok, *dn, *ddone, *dpl;
     CK(hipMalloc(&dtok, tok.size() * 4)); CK(hipMemcpy(dtok, tok.data(), tok.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dn, 4)); CK(hipMemcpy(dn, nrows.data(), 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&ddone, B * 4)); CK(hipMemcpy(ddone, done.data(), B * 4, hipMemcpyHostToDevice));
-    CK(hipMalloc(&dpc, nteams * 4)); CK(hipMemcpy(dpc, pcount.data(), nteams * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dpl, plist.size() * 4)); CK(hipMemcpy(dpl, plist.data(), plist.size() * 4, hipMemcpyHostToDevice));
-    a.tok = dtok; a.ldtok = max_len + 1; a.nrows = dn; a.done = ddone; a.pcount = dpc; a.plist = dpl;
+    a.tok = dtok; a.ldtok = max_len + 1; a.nrows = dn; a.done = ddone; a.plist = dpl;
     const size_t ctr_words = (size_t)nteams * 32 + 32;
     unsigned* ctr;
     CK(hipMalloc(&ctr, ctr_words * 4));
