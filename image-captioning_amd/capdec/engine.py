@@ -291,7 +291,8 @@ def tf_beam_ids(dec, enc, beam_width, max_length, sos, eos, return_scores=False,
     the reference lets attend uniformly over the current length: no cache can hold that) are then redone with the
     full-prefix form, so the captions are the reference's in every case.  ``exact=True`` uses the full-prefix form for
     every sample.  (The reference leaves its loop when ALL hypotheses of the batch produce <EOS> in one step; a redone
-    subset is a batch of its own in that respect, which can only matter for the scores, never for the captions.)"""
+    subset is a batch of its own in that respect: its loop can end earlier than the full batch's did, which changes the
+    scores and, only where two hypotheses tie exactly at that step, could change which of them is returned.)"""
     lib = _lib.load()
     if not enc.is_cuda or enc.dtype != torch.float32:
         raise RuntimeError("capdec: enc must be an fp32 tensor on the GPU (HIP); there is no CPU path")

@@ -1286,6 +1286,23 @@ int capdec_bgemm(const capdec_bgemm_desc* a, int form, void* stream) {
 int capdec_vocab_tiles(int V) { return (V + VOCAB_BI - 1) / VOCAB_BI; }
 size_t capdec_vocab_partial_elems(int M, int V) { return (M < 0 || V < 1) ? 0 : capdec_part_elems(M, capdec_vocab_tiles(V)); }
 
+// Readiness of vocab_argmax_small_kernel per device: 0 unknown, 1 ready, -1 the attribute call failed there.  An
+// attribute call is not made while `s` is being captured (it is not a stream operation and would end the capture with
+// an error of its own): the caller then takes the general tiling for this call.
+static std::mutex g_vs_mutex;
+static signed char g_vs_state[64];
+static bool vocab_small_ready(hipStream_t s) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(g_vs_mutex);
+    if (g_vs_state[dev] == 0) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+        g_vs_state[dev] = allow_lds(vocab_argmax_small_kernel, VS_LDS_BYTES) ? 1 : -1;
+    }
+    return g_vs_state[dev] == 1;
+}
+
 static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const float* W, const float* bias, int M, int V,
                                int K, float* out_a, void* out_b, hipStream_t s, const int32_t* rows_dev = nullptr) {
     CAPDEC_REQUIRE(x && W && bias && out_a && out_b && M >= 0 && V >= 1 && K >= 1 && ldx >= K);
@@ -1295,12 +1312,14 @@ static int vocab_reduce_launch(int mode, const float* x, int64_t ldx, const floa
     if (mode == 0 && M <= VS_MAX_ROWS && vec && K % 32 == 0 && g_staging != 1) {
         // a small batch (the reference's loaders default to 32 and 64 rows): one workgroup of eight wavefronts per
         // vocabulary tile and block of 32 rows
-        static const bool ready = allow_lds(vocab_argmax_small_kernel, VS_LDS_BYTES);
-        if (!ready) return CAPDEC_EINVAL;
-        hipLaunchKernelGGL(vocab_argmax_small_kernel, dim3(nt, (M + 31) / 32), dim3(512), VS_LDS_BYTES, s, W, x, ldx, bias, V, M, K, out_a,
-                           static_cast<int*>(out_b), nt, rows_dev);
-        CAPDEC_LAUNCH_CHECK();
-        return 0;
+        // (its LDS limit is raised once per device, with that device current; where that fails, and while a stream is
+        //  being captured before it has happened, the general tiling below takes the same shapes)
+        if (vocab_small_ready(s)) {
+            hipLaunchKernelGGL(vocab_argmax_small_kernel, dim3(nt, (M + 31) / 32), dim3(512), VS_LDS_BYTES, s, W, x, ldx, bias, V, M, K, out_a,
+                               static_cast<int*>(out_b), nt, rows_dev);
+            CAPDEC_LAUNCH_CHECK();
+            return 0;
+        }
     }
     // samples sit on the j (lane) axis: 128-wide tiles when there are enough rows to fill the chip
     const bool wide = ((long)nt * ((M + 127) / 128) >= 192);
@@ -1371,13 +1390,16 @@ static std::mutex g_scratch_mutex;
 static unsigned char* g_scratch_ptr[STATIC_MAX_DEVICES];     // per device; nullptr until resolved on that device
 
 // Device address of `scratch` on the current device (resolved once per device, with that device current).
-static int scratch_address(unsigned char** out) {
+static int scratch_address(unsigned char** out, hipStream_t stream) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= STATIC_MAX_DEVICES) return CAPDEC_EINVAL;
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
+        // the first call on a device resolves the address: not under stream capture (make one call before capturing)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return CAPDEC_EINVAL;
         void* ptr = nullptr;
         e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return (int)e;
@@ -1395,7 +1417,7 @@ int capdec_vocab_argmax_static(const float* x, int64_t ldx, const float* W, cons
     if (elems > VOCAB_STATIC_ELEMS) return CAPDEC_E2BIG;
     if (M == 0) return 0;
     unsigned char* base = nullptr;
-    CAPDEC_TRY(scratch_address(&base));
+    CAPDEC_TRY(scratch_address(&base, (hipStream_t)stream));
     // values first, ids behind them; every (row < M, tile) slot that the merge reads is written by the projection
     // kernel of the same call, so nothing has to be cleared between calls
     float* part_val = reinterpret_cast<float*>(base);

@@ -98,3 +98,32 @@ def test_static_vocab_argmax_rejects_sizes_beyond_its_array():
     _lib.check(_static(lib, x, W, b, idx, val), "capdec_vocab_argmax_static")
     widx, wval = _two_call(lib, x, W, b)
     assert torch.equal(idx, widx) and torch.equal(val, wval)
+
+
+@pytest.mark.parametrize("M", [1024, 32])
+def test_static_vocab_argmax_under_stream_capture(M):
+    """What the entry point exists for: after one call outside capture (it resolves the array's address on the device)
+    the call is captured into a HIP graph - an allocation inside the captured region would end the capture with an
+    error - and replayed with changed inputs; every replay must equal the two-call form on the inputs of that replay."""
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    V, K = 5000, 512
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(V, K, generator=g) / K ** 0.5).to(dev)
+    b = (0.1 * torch.randn(V, generator=g)).to(dev)
+    idx = torch.full((M,), -7, dtype=torch.int32, device=dev)
+    val = torch.zeros(M, dtype=torch.float32, device=dev)
+    _lib.check(_static(lib, x, W, b, idx, val), "capdec_vocab_argmax_static")          # warm-up outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _lib.check(_static(lib, x, W, b, idx, val), "capdec_vocab_argmax_static (captured)")
+    for seed in (1, 2):
+        g2 = torch.Generator().manual_seed(100 * M + seed)
+        x.copy_(torch.randn(M, K, generator=g2))
+        idx.fill_(-7)
+        graph.replay()
+        torch.cuda.synchronize()
+        widx, wval = _two_call(lib, x, W, b)
+        assert torch.equal(idx, widx) and torch.equal(val, wval), seed
