@@ -55,7 +55,7 @@ def main():
     mfma("gemm_kernel 32x64 BK16 grouped (decode Q,K,V)", "3 x 1024x512x512", 6.0 * M * E * E,
          lambda: ops.gemm_groups([dict(P=x, Q=w, C=o) for w, o in zip(Ws, outs)], E))
     Wv, bv = rnd(V, E), rnd(V)
-    mfma("vocab_reduce_kernel (projection + arg-max)", "1024x10000x512", 2.0 * M * V * E, lambda: ops.vocab_argmax(x, Wv, bv))
+    mfma("ops.vocab_argmax: vocab_reduce_kernel + the merge launch + two output allocations (the kernel alone: kernel statistics)", "1024x10000x512", 2.0 * M * V * E, lambda: ops.vocab_argmax(x, Wv, bv))
     gam, bet = torch.ones(E, device="cuda"), torch.zeros(E, device="cuda")
     y = torch.empty(M, E, device="cuda")
     hbm("add_layernorm_kernel (decode)", "1024x512, x+add->y", 3.0 * M * E * 4, lambda: ops.add_layernorm(x, gam, bet, add=out, out=y))

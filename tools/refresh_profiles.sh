@@ -19,3 +19,7 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_mfma_trace -o p -- python3 $R/tools/mfma_workload.py > $O/${tag}_mfma_trace.log 2>&1
 python3 $R/tools/mfma_util.py $O/${tag}_mfma_pmc/p_counter_collection.csv $O/${tag}_mfma_trace/p_kernel_trace.csv > $O/${tag}_mfma_util.md
 echo mfma done
+# kernels that only the secondary workloads launch: kernel statistics of the whole bench line, variants included
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_vstats -o p -- python3 $R/bench.py --steps 3 --warmup 1 --train-steps 3 --no-cpu-baseline > $O/${tag}_vstats.log 2>&1
+python3 $R/tools/variant_roofline.py $O/${tag}_vstats/p_kernel_stats.csv > $O/${tag}_variant_roofline.md
+echo variants done

@@ -20,8 +20,10 @@ ROWS = [
      2 * B * (12 * E * E + 4 * 10.5 * E) * 2.0 / 2, "q/k/v/o/fc1/fc2 of both layers + self-attention; 12 E^2 + 4 t E FLOP per row and layer"),
     ("ln_pair_kernel", "cfg4 / cfg5 decode: 1024 rows, two memory rows", "hbm", (3 + 2 * H) * E * 4.0 * B, "(3 + 2H) E floats per row"),
     ("attention_memory_kernel", "cfg4-as-worded decode: 1024 rows x 261 raw memory rows", "hbm", 1.0 * B * 261 * E * 4, "the memory once per row"),
-    ("pair_gate_fwd_kernel", "cfg4 training: live rows of 512 x 20 (about 7.5 k), H=4", "hbm", 7488 * (2 + 2 * H) * E * 4.0, "x1, a2 + G, D per head"),
-    ("pair_gate_bwd_kernel", "cfg4 training: the same rows", "hbm", 7488 * (3 + 2 * H) * E * 4.0, "d_a2, x1, d_x1 + G, D per head"),
+    ("pair_gate_fwd_kernel", "cfg4 training: live rows of 512 x 20 (about 7.5 k), H=4", "hbm", 7488 * 2 * E * 4.0 + 512 * (2 * H + 1) * E * 4.0,
+     "x1 read, a2 written per row; G, D per head and c1 once per sample (the 20 rows of a sample share them in cache)"),
+    ("pair_gate_bwd_kernel", "cfg4 training: the same rows", "hbm", 7488 * 3 * E * 4.0 + 512 * 4 * H * E * 4.0,
+     "d_a2, x1 read, d_x1 written per row; G, D read and their gradients written once per sample"),
     ("additive_attention_bwd_kernel", "soft-attention LSTM training: B=512, S=64, A=512, E=512, per time step", "hbm",
      512 * 64 * (2 * 512 + 2 * E) * 4.0, "pf, enc read, dpf, denc accumulated"),
     ("additive_attention_kernel", "soft-attention LSTM decode/training step: B=1024/512, S=64 (mixed)", "hbm", 768 * 64 * (512 + E) * 4.0,
