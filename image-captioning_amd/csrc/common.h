@@ -103,7 +103,7 @@ int capdec_launch_attention_memory_rows(const float* qp, int64_t ldq, const floa
 // Rows are cut into blocks of CAPDEC_FUSED_ROWS, each walked through the layers by a team of CAPDEC_FUSED_TEAM workgroups;
 // a team carries up to CAPDEC_FUSED_SIDE_ROWS earlier <PAD> positions of its samples along (two layers only).
 #define CAPDEC_FUSED_TEAM 8
-#define CAPDEC_FUSED_ROWS 32
+#define CAPDEC_FUSED_ROWS 16
 #define CAPDEC_FUSED_SIDE_ROWS 16
 #define CAPDEC_FUSED_MAX_LAYERS 2
 struct capdec_fused_layer {
@@ -135,6 +135,7 @@ struct capdec_fused_args {
     unsigned* err;            // raised by a workgroup whose bounded wait ran out
     unsigned long long* trace;   // probe builds only (CAPDEC_FUSED_TRACE): [8][64] stage timestamps of team trace_team
     int trace_team;
+    unsigned* hwid;              // probe builds only: [grid] hardware id register of each workgroup's first wavefront
 };
 bool capdec_fused_layers_supported(int E, int H, int L, int64_t B, int max_len);
 int capdec_launch_fused_layers(const capdec_fused_args& a, int E, hipStream_t s);

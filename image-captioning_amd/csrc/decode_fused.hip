@@ -6,34 +6,36 @@
 // own cache -> output projection + residual -> LayerNorm 1, + cross-attention constant, LayerNorm 2 -> fc1 + ReLU ->
 // fc2 + residual -> LayerNorm 3, and again for the next layer.  No operation mixes rows of different samples.  As
 // separate launches every link of that chain pays a kernel boundary and a cold start (7 launches per layer, each about
-// 7 us of fixed cost for 5 us of matrix work at 1024 rows).  Here the rows are cut into blocks of 32 and each block is
-// given to a TEAM of 8 workgroups that walks the whole chain for it:
+// 7 us of fixed cost for 5 us of matrix work at 1024 rows).  Here the rows are cut into blocks of 16 and each block is
+// given to a TEAM of 8 workgroups that walks the whole chain for it (78 KB of LDS and at most 128 registers per lane:
+// two workgroups share a CU from 513 rows on, one fills the wait of the other):
 //   - a workgroup owns E/8 output columns of every projection (64 at E = 512) and the rows' full contraction depth:
-//     its 8 wavefronts split the contraction (k-slabs of E/8), hold the activations as MFMA fragments in REGISTERS,
-//     stream their weight slab through a two-slot LDS ring with global_load_lds (the next operation's slab is already
+//     its 8 wavefronts split the contraction (k-slabs of E/8), hold the activations as MFMA fragments in REGISTERS
+//     (16 x 16 x 4 fp32 tiles), stream their weight slab through a two-slot LDS ring with global_load_lds in entries of
+//     32 columns x 32 k per wavefront (the next operation's slab is already
 //     on its way while the team waits for its members), sum the 8 partial tiles through LDS and apply bias / ReLU /
 //     residual;
-//   - between operations the 8 members exchange their 32 x E/8 slices through global memory in a fragment-major
+//   - between operations the 8 members exchange their 16 x E/8 slices through global memory in a fragment-major
 //     layout ([k/4][row][4 floats]: the 16-byte fragment loads of a consumer are contiguous 1 KiB runs), written with
 //     write-through (sc1) 16-byte stores, published by one agent-scope atomic add per workgroup behind a drain of
 //     every storing wavefront and a workgroup barrier, and read with sc1 loads behind a relaxed poll of that counter
 //     by one lane and a workgroup barrier; teams never wait for one another;
 //   - LayerNorm runs on the fragments in registers (row sums over the 8 k-slabs meet in LDS), redundantly in the 8
 //     members, so it costs no hand-off of its own;
-//   - attention: a member takes one head for 16 of the 32 rows (two (row, head) pairs per wavefront).
+//   - attention: a member takes one head for 8 of the 16 rows (two (row, head) pairs per wavefront, four wavefronts).
 //
 // Generated <PAD> tokens.  The reference masks a <PAD> QUERY row, which then attends uniformly over the CURRENT length
 // (transformer.py:117-123), so the layer-0 output of such a position changes at every later step.  Layer-0 keys and
 // values depend on the embeddings only and the causal rows around it never see the difference in layer 0; what
 // changes is the <PAD> position's INPUT TO LAYER 1, i.e. its layer-1 key and value, which the sample's newest row
 // attends to.  (Later rows' layer-1 outputs change too, but with two layers nothing reads them.)  So a team carries
-// the <PAD> positions of its own samples along as up to 16 SIDE rows (a 16-row MFMA tile next to the 32-row one, on
-// the same weight slabs): mean of the layer-0 values -> output projection -> LayerNorms -> FFN -> LayerNorm 3 ->
+// the <PAD> positions of its own samples along as up to 16 SIDE rows (a second 16-row tile that follows the main one
+// through each operation of layer 0, on the same weight slices streamed once more): mean of the layer-0 values -> output projection -> LayerNorms -> FFN -> LayerNorm 3 ->
 // layer-1 key and value, written to the cache before the team's layer-1 attention reads them.  With one layer nothing
 // has to be re-run at all.  A team whose samples hold more than 16 <PAD> positions flags the surplus samples for the
 // exact path (out_dirty).
 // The launch of step t >= 1 also finishes step t-1: every member merges the per-tile arg-max winners of the previous
-// vocabulary projection for its team's 32 rows (the token ids it needs for the embedding rows anyway), member 0 does the
+// vocabulary projection for its team's 16 rows (the token ids it needs for the embedding rows anyway), member 0 does the
 // reference's bookkeeping for them (transformer.py:155-171), and the input rows are built in registers: no separate
 // token-pick launch, no round trip of the input rows through memory.
 // Progress: a team only ever waits for its own members; workgroups are dispatched in index order, so the members of the
@@ -43,6 +45,9 @@
 #include <limits.h>
 #include <math.h>
 #include <mutex>
+#ifdef CAPDEC_FUSED_TRACE
+#include <stdlib.h>
+#endif
 
 namespace {
 
@@ -60,29 +65,33 @@ template <int E>
 struct FT {
     static constexpr int NC = E / FT_TEAM;            // output columns of a workgroup
     static constexpr int KW = E / FT_WAVES;           // contraction range of a wavefront
-    static constexpr int NH = KW / 32;                // 32-deep half-slabs per wavefront and projection
-    static constexpr int NT = NC / 32;                // 32x32 accumulators per wavefront
-    static constexpr int NA = KW / 8;                 // 16-byte activation fragments per lane (32-row tile)
-    static constexpr int NS = KW / 16;                // the same of the 16-row side tile
-    static constexpr int NCT = NC / 16;               // 16x16 accumulators per wavefront (side tile)
-    static constexpr int PIECES = NC / 8;             // global_load_lds instructions per half-slab (8 rows x 128 B each)
-    static constexpr int WSLAB = NC * 32;             // floats of one wavefront's half-slab [NC][32]
+    static constexpr int NF = KW / 16;                // 16-byte activation fragments per lane (16-row tile)
+    static constexpr int NCT = NC / 16;               // 16x16 accumulators per wavefront and projection
+    static constexpr int NE = 4;                      // ring entries per projection: (column half, k half)
+    static constexpr int PIECES = 4;                  // global_load_lds instructions per entry (8 rows x 128 B each)
+    static constexpr int WSLAB = 32 * 32;             // floats of one wavefront's entry image [32 columns][32 k]
     static constexpr int WSLOT = FT_WAVES * WSLAB;
     static constexpr int DK = E / 4;                  // head width (H == 4)
-    static constexpr int CST_LD = DK + 4;
     static constexpr int OFF_W0 = 0;
     static constexpr int OFF_W1 = WSLOT;              // second ring slot; the k-split partial tiles between operations
-    static constexpr int OFF_R = 2 * WSLOT;           // [NC/4][32][4] own columns of the residual operand (main rows)
-    static constexpr int OFF_RS = OFF_R + 32 * NC;    // [NC/4][16][4] the same of the side rows
-    static constexpr int OFF_CST = OFF_RS + 16 * NC;  // [16][DK+4] attention outputs before they are stored
-    static constexpr int OFF_PART = OFF_CST + 16 * CST_LD;      // [2][8][32] LayerNorm partial sums
-    static constexpr int OFF_SC = OFF_PART + 2 * FT_WAVES * 32; // [8][2][64] probability rows (two (row, head) pairs per wavefront)
-    static constexpr int OFF_META = OFF_SC + FT_WAVES * 128;    // ints: row descriptors, wait flag
-    static constexpr int LDS_FLOATS = OFF_META + 4 * 32 + 4 * 16 + 16;
-    static_assert(NH == 2 && NT >= 1 && KW == NC && NC == 64, "team kernel built for E = 512");
+    static constexpr int OFF_R = 2 * WSLOT;           // [NC/4][16][4] own columns of the residual operand (main rows)
+    static constexpr int OFF_RS = OFF_R + 16 * NC;    // [NC/4][16][4] the same of the side rows (fc2 only) ...
+    static constexpr int OFF_CST = OFF_RS;            // ... and, in the attention stage, [8][DK] outputs before they are stored
+    static constexpr int OFF_PART = OFF_RS + 16 * NC; // [2][8][16] LayerNorm partial sums
+    static constexpr int OFF_SC = OFF_PART + 2 * FT_WAVES * 16;   // [4][2][64] probability rows (two (row, head) pairs per wavefront)
+    static constexpr int OFF_META = OFF_SC + 4 * 128; // ints: row descriptors, wait flag
+    static constexpr int LDS_FLOATS = OFF_META + 160;
+    static_assert(NF == 4 && NCT == 4 && KW == NC && NC == 64 && 8 * DK == 16 * NC, "team kernel built for E = 512");
+    static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
 };
 
-__device__ __forceinline__ int acc_row32(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+// The lane id again, opaque to the optimiser: index arithmetic that starts from it is redone where it is used instead of
+// being kept in a register from the top of the kernel (at 128 registers per lane such values get spilled, and a reload
+// from scratch memory waits for every store and weight load the wavefront has in flight).
+__device__ __forceinline__ int fresh(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 
 __device__ __forceinline__ f32x4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, FT_SC1));
@@ -91,10 +100,10 @@ __device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t rs, unsigned by
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs, (int)byte_off, 0, FT_SC1);
 }
 
-// one half-slab of a weight slice, straight into this wavefront's part of a ring slot: LDS image [NC][32] floats with
-// the 16-byte slots of a row XOR-swizzled by (row >> 1) & 7 (conflict-free 16-byte fragment reads of 16 or 32 rows).
-// Piece p (8 rows of 128 bytes) of the image comes from rows p*8 + lane/8; the swizzle of a lane's slot depends on p
-// through p & 1 only, so two per-lane offsets serve all pieces and everything else is wavefront-uniform.
+// One ring entry of a weight slice, straight into this wavefront's part of a ring slot: 32 output columns x 32 k, LDS
+// image [32][32] floats with the 16-byte slots of a row XOR-swizzled by (row >> 1) & 7 (conflict-free 16-byte fragment
+// reads of 16 rows).  Piece p (8 rows of 128 bytes) of the image comes from rows p*8 + lane/8; the swizzle of a lane's
+// slot depends on p through p & 1 only, so two per-lane offsets serve all pieces and everything else is uniform.
 struct LaneOff { int even, odd; };
 template <int E>
 __device__ __forceinline__ LaneOff lane_offsets(int lane) {
@@ -104,127 +113,74 @@ __device__ __forceinline__ LaneOff lane_offsets(int lane) {
     o.odd = (r8 * E + ((c ^ ((4 + (r8 >> 1)) & 7)) << 2)) * 4;
     return o;
 }
+// entry e of a projection: column half e >> 1, k half e & 1
 template <int E>
-__device__ __forceinline__ void issue_half(const float* __restrict__ W, int member, int wave, LaneOff lo, int half,
-                                           float* slot) {
+__device__ __forceinline__ void issue_entry(const float* __restrict__ W, int member, int wave, LaneOff lo, int e, float* slot) {
     using C = FT<E>;
     float* dst = slot + wave * C::WSLAB;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, E * E * 4, 0x00020000);
-    const int base = ((member * C::NC) * E + wave * C::KW + half * 32) * 4;      // uniform
-#ifndef FT_W_AUX
-#define FT_W_AUX 0
-#endif
-#ifndef FT_EXPERIMENT_NO_DMA      // timing experiment only (tools/exp): the contractions then read whatever LDS holds
+    const int base = ((member * C::NC + (e >> 1) * 32) * E + wave * C::KW + (e & 1) * 32) * 4;      // uniform
 #pragma unroll
     for (int p = 0; p < C::PIECES; ++p)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + p * 256), 16,
-                                                 (p & 1) ? lo.odd : lo.even, base + p * 8 * E * 4, 0, FT_W_AUX);
-#endif
+                                                 (p & 1) ? lo.odd : lo.even, base + p * 8 * E * 4, 0, 0);
 }
 
-// 32 rows: lane (r, h) holds a[kc] = X[r][k0 + kc*8 + 4h + {0..3}]; MFMA m of chunk kc sums k in {kc*8+m, kc*8+4+m}
+// 16 rows: lane (c, g) holds a[kq] = X[c][k0 + kq*16 + 4g + {0..3}]; MFMA m of chunk kq sums k in {kq*16 + 4g' + m};
+// accumulator register e of lane (c, g) is row 4g + e, column ct*16 + c
 template <int E>
-__device__ __forceinline__ void mma_half(const float* slot, int wave, int lane, const f32x4* a, f32x16 (&acc)[FT<E>::NT]) {
-    using C = FT<E>;
-    const int r = lane & 31, h = lane >> 5;
-    const float* img = slot + wave * C::WSLAB;
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-        f32x4 b[C::NT];
-#pragma unroll
-        for (int t = 0; t < C::NT; ++t) {
-            const int row = t * 32 + r;
-            b[t] = *reinterpret_cast<const f32x4*>(img + row * 32 + ((((kc * 2 + h) ^ ((row >> 1) & 7))) << 2));
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int t = 0; t < C::NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][m], b[t][m], acc[t], 0, 0, 0);
-    }
-}
-// 16 side rows: lane (c, g) holds as[kq] = X[c][k0 + kq*16 + 4g + {0..3}]; MFMA m of chunk kq sums k in {kq*16 + 4g' + m}
-template <int E>
-__device__ __forceinline__ void mma_half_side(const float* slot, int wave, int lane, const f32x4* as,
-                                              f32x4 (&acc)[FT<E>::NCT]) {
+__device__ __forceinline__ void mma_entry(const float* slot, int wave, int lane, const f32x4* a2, f32x4* acc2) {
     using C = FT<E>;
     const int c = lane & 15, g = lane >> 4;
     const float* img = slot + wave * C::WSLAB;
 #pragma unroll
     for (int kq = 0; kq < 2; ++kq) {
 #pragma unroll
-        for (int ct = 0; ct < C::NCT; ++ct) {
+        for (int ct = 0; ct < 2; ++ct) {
             const int row = ct * 16 + c;
             const f32x4 b = *reinterpret_cast<const f32x4*>(img + row * 32 + ((((kq * 4 + g) ^ ((row >> 1) & 7))) << 2));
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[kq][m], b[m], acc[ct], 0, 0, 0);
+            for (int m = 0; m < 4; ++m) acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kq][m], b[m], acc2[ct], 0, 0, 0);
         }
     }
 }
 
-// NPROJ projections streamed through the ring.  The stream of half-slabs W[0] half 0, W[0] half 1, W[1] half 0, ...
+// NPROJ projections of the 16-row tile streamed through the ring.  The stream of entries W[0] e0..e3, W[1] e0.., ...
 // alternates between the two ring slots; its first two entries were issued before the call, entry n + 2 is issued as
-// soon as this wavefront has read entry n, and once slot 0 is free for good the first half-slab of `next` (the next
+// soon as this wavefront has read entry n, and once slot 0 is free for good the first entry of `next` (the next
 // operation's weights; nullable) follows.  Nothing else of this wavefront is in flight inside the loop, so the counted
-// waits see exactly the ring's loads (they retire in order).  Projection p multiplies the 32-row tile when bit p of
-// MAIN_MASK is set (accumulators acc[0], acc[1], ... in projection order) and the 16-row side tile when bit p of
-// SIDE_MASK is set and `side` holds (uniform over the workgroup; accumulators accs[0], ...).
-constexpr int popcount_c(int m) { return m ? (m & 1) + popcount_c(m >> 1) : 0; }
-constexpr int atleast1(int n) { return n < 1 ? 1 : n; }
-template <int E, int NPROJ, int MAIN_MASK, int SIDE_MASK>
+// waits see exactly the ring's loads (they retire in order).
+template <int E, int NPROJ>
 __device__ __forceinline__ void gemm_stream(float* lds, const float* const (&W)[NPROJ], const float* next, int member,
-                                            int wave, int lane, LaneOff lo, const f32x4 (&a)[FT<E>::NA],
-                                            f32x16 (&acc)[atleast1(popcount_c(MAIN_MASK))][FT<E>::NT], bool side,
-                                            const f32x4 (&as)[FT<E>::NS],
-                                            f32x4 (&accs)[atleast1(popcount_c(SIDE_MASK))][FT<E>::NCT]) {
+                                            int wave, int lane, LaneOff lo, const f32x4 (&a)[FT<E>::NF],
+                                            f32x4 (&acc)[NPROJ][FT<E>::NCT]) {
     using C = FT<E>;
-    constexpr int N = NPROJ * C::NH;
+    constexpr int N = NPROJ * C::NE;
     float* slot0 = lds + C::OFF_W0;
     float* slot1 = lds + C::OFF_W1;
 #pragma unroll
-    for (int p = 0; p < popcount_c(MAIN_MASK); ++p)
+    for (int p = 0; p < NPROJ; ++p)
 #pragma unroll
-        for (int t = 0; t < C::NT; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[p][t][e] = 0.f;
-#pragma unroll
-    for (int p = 0; p < popcount_c(SIDE_MASK); ++p)
-#pragma unroll
-        for (int t = 0; t < C::NCT; ++t) accs[p][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < C::NCT; ++t) acc[p][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         if (n == 0 || (n == N - 1 && !next)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PIECES) : "memory");
-        const int p = n / C::NH, hf = n % C::NH;
-        const float* slot = (n & 1) ? slot1 : slot0;
-        if ((MAIN_MASK >> p) & 1) mma_half<E>(slot, wave, lane, &a[hf * 4], acc[popcount_c(MAIN_MASK & ((1 << p) - 1))]);
-        if (((SIDE_MASK >> p) & 1) && side)
-            mma_half_side<E>(slot, wave, lane, &as[hf * 2], accs[popcount_c(SIDE_MASK & ((1 << p) - 1))]);
+        const int p = n / C::NE, e = n % C::NE;
+        float* slot = (n & 1) ? slot1 : slot0;
+        mma_entry<E>(slot, wave, lane, &a[(e & 1) * 2], &acc[p][(e >> 1) * 2]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wavefront's fragment reads of the slot are done
-        if (n + 2 < N) issue_half<E>(W[(n + 2) / C::NH], member, wave, lo, (n + 2) % C::NH, (n & 1) ? slot1 : slot0);
-        else if (n + 2 == N && next) issue_half<E>(next, member, wave, lo, 0, slot0);
+        if (n + 2 < N) issue_entry<E>(W[(n + 2) / C::NE], member, wave, lo, (n + 2) % C::NE, slot);
+        else if (n + 2 == N && next) issue_entry<E>(next, member, wave, lo, 0, slot0);
     }
 }
 
-// this wavefront's 32 x NC partial tile into its own part of slot 1 (exactly the bytes of its half-slab: no other
-// wavefront's weights are overwritten); 16-byte slots of a row XOR-swizzled by row & 15
+// this wavefront's 16 x NC partial tile into its own part of slot 1 (exactly the bytes of its entry image: no other
+// wavefront's weights are overwritten); 16-byte slots of a row XOR-swizzled by the row
 template <int E>
-__device__ __forceinline__ void write_partial(float* lds, int wave, int lane, const f32x16 (&acc)[FT<E>::NT]) {
+__device__ __forceinline__ void write_partial(float* lds, int wave, int lane, const f32x4 (&acc)[FT<E>::NCT]) {
     using C = FT<E>;
-    const int r = lane & 31, h = lane >> 5;
-    float* d = lds + C::OFF_W1 + wave * C::WSLAB;
-#pragma unroll
-    for (int t = 0; t < C::NT; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = acc_row32(e, h), j = t * 32 + r;
-            d[i * C::NC + ((((j >> 2) ^ (i & 15)) << 2) | (j & 3))] = acc[t][e];
-        }
-}
-// the 16 x NC partial tile of the side rows: register e of lane (c, g) is row 4g + e, column ct*16 + c
-template <int E>
-__device__ __forceinline__ void write_partial_side(float* lds, int wave, int lane, const f32x4 (&acc)[FT<E>::NCT]) {
-    using C = FT<E>;
+    lane = fresh(lane);
     const int c = lane & 15, g = lane >> 4;
     float* d = lds + C::OFF_W1 + wave * C::WSLAB;
 #pragma unroll
@@ -232,13 +188,13 @@ __device__ __forceinline__ void write_partial_side(float* lds, int wave, int lan
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e, j = ct * 16 + c;
-            d[i * C::NC + ((((j >> 2) ^ (i & 15)) << 2) | (j & 3))] = acc[ct][e];
+            d[i * C::NC + ((((j >> 2) ^ i) << 2) | (j & 3))] = acc[ct][e];
         }
 }
 template <int E>
 __device__ __forceinline__ f32x4 sum_partials(const float* lds, int i, int sl) {
     using C = FT<E>;
-    const float* p = lds + C::OFF_W1 + i * C::NC + ((sl ^ (i & 15)) << 2);
+    const float* p = lds + C::OFF_W1 + i * C::NC + ((sl ^ i) << 2);
     f32x4 v = *reinterpret_cast<const f32x4*>(p);
 #pragma unroll
     for (int w = 1; w < FT_WAVES; ++w) v += *reinterpret_cast<const f32x4*>(p + w * C::WSLAB);
@@ -260,10 +216,6 @@ __device__ __forceinline__ void team_signal(unsigned* flags, int member, unsigne
 // Lanes 0..7 of the first wavefront poll the eight flags (relaxed, L1-bypassing), the workgroup meets behind them;
 // false (for every thread) when the spin ran out.
 __device__ __forceinline__ bool team_wait(unsigned* flags, unsigned epoch, unsigned* err, int* flag) {
-#ifdef FT_EXPERIMENT_NO_WAIT      // timing experiment only (tools/exp): results are garbage
-    wg_barrier();
-    return true;
-#endif
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         unsigned spins = 0;
@@ -284,59 +236,58 @@ __device__ __forceinline__ bool team_wait(unsigned* flags, unsigned epoch, unsig
     return flag[epoch & 1] != 0;     // (two words in turn: the next wait writes the other one)
 }
 
-// Fragments of a [k/4][ROWS][4] exchange block: lane (row, g) of wavefront w loads the 16-byte slots w*KW/4 + kf*G + g
-template <int E, int NF, int RB>
-__device__ __forceinline__ void load_frags(__amdgpu_buffer_rsrc_t rs, int wave, int lane, f32x4 (&a)[NF]) {
+// Fragments of a [k/4][16][4] exchange block: lane (row, g) of wavefront w loads the 16-byte slots w*KW/4 + kf*4 + g
+template <int E>
+__device__ __forceinline__ void load_frags(__amdgpu_buffer_rsrc_t rs, int wave, int lane, f32x4 (&a)[FT<E>::NF]) {
     using C = FT<E>;
-    constexpr int ROWS = 1 << RB, G = 64 >> RB;
-    const int row = lane & (ROWS - 1), g = lane >> RB;
+    lane = fresh(lane);
+    const int row = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int kf = 0; kf < NF; ++kf) a[kf] = load_sc1(rs, (unsigned)(((wave * (C::KW / 4) + kf * G + g) * ROWS + row) * 16));
+    for (int kf = 0; kf < C::NF; ++kf) a[kf] = load_sc1(rs, (unsigned)(((wave * (C::KW / 4) + kf * 4 + g) * 16 + row) * 16));
 }
 
-// LayerNorm (eps 1e-5, affine) of rows held as fragments: lane (row, g) of wavefront w holds the columns
-// w*KW + kf*4G + 4g + {0..3} of its row (32 rows: G = 2; 16 rows: G = 4).  Two-pass mean / variance; the 8 wavefronts'
-// row sums meet in LDS.
-template <int E, int NF, int RB>
-__device__ __forceinline__ void ln_frags(f32x4 (&a)[NF], const float* __restrict__ gamma, const float* __restrict__ beta,
+// LayerNorm (eps 1e-5, affine) of 16 rows held as fragments: lane (row, g) of wavefront w holds the columns
+// w*KW + kf*16 + 4g + {0..3} of its row.  Two-pass mean / variance; the 8 wavefronts' row sums meet in LDS.
+template <int E>
+__device__ __forceinline__ void ln_frags(f32x4 (&a)[FT<E>::NF], const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* part, int& pb, int wave, int lane) {
     using C = FT<E>;
-    constexpr int ROWS = 1 << RB, G = 64 >> RB;
-    const int row = lane & (ROWS - 1), g = lane >> RB;
+    lane = fresh(lane);
+    const int row = lane & 15, g = lane >> 4;
     float s = 0.f;
 #pragma unroll
-    for (int kf = 0; kf < NF; ++kf) s += (a[kf][0] + a[kf][1]) + (a[kf][2] + a[kf][3]);
-#pragma unroll
-    for (int o = ROWS; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
-    float* p = part + pb * (FT_WAVES * 32);
+    for (int kf = 0; kf < C::NF; ++kf) s += (a[kf][0] + a[kf][1]) + (a[kf][2] + a[kf][3]);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    float* p = part + pb * (FT_WAVES * 16);
     pb ^= 1;
-    if (g == 0) p[wave * 32 + row] = s;
+    if (g == 0) p[wave * 16 + row] = s;
     wg_barrier();
     float tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 32 + row];
+    for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 16 + row];
     const float mean = tot / (float)E;
     float q = 0.f;
 #pragma unroll
-    for (int kf = 0; kf < NF; ++kf) {
+    for (int kf = 0; kf < C::NF; ++kf) {
         a[kf] -= mean;
         q += (a[kf][0] * a[kf][0] + a[kf][1] * a[kf][1]) + (a[kf][2] * a[kf][2] + a[kf][3] * a[kf][3]);
     }
-#pragma unroll
-    for (int o = ROWS; o < 64; o <<= 1) q += __shfl_xor(q, o, 64);
-    p = part + pb * (FT_WAVES * 32);
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    p = part + pb * (FT_WAVES * 16);
     pb ^= 1;
-    if (g == 0) p[wave * 32 + row] = q;
+    if (g == 0) p[wave * 16 + row] = q;
     wg_barrier();
     tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 32 + row];
+    for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 16 + row];
     const float rstd = 1.0f / sqrtf(tot / (float)E + 1e-5f);
     const int c0 = wave * C::KW + 4 * g;
 #pragma unroll
-    for (int kf = 0; kf < NF; ++kf) {
-        const f32x4 gg = *reinterpret_cast<const f32x4*>(gamma + c0 + kf * 4 * G);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c0 + kf * 4 * G);
+    for (int kf = 0; kf < C::NF; ++kf) {
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(gamma + c0 + kf * 16);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c0 + kf * 16);
         a[kf] = a[kf] * rstd * gg + bb;
     }
 }
@@ -356,18 +307,23 @@ __device__ __forceinline__ void ln_frags(f32x4 (&a)[NF], const float* __restrict
 #endif
 
 template <int E>
-__global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_fused_args A) {
+__global__ __launch_bounds__(FT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void decode_layers_team_kernel(capdec_fused_args A) {
     using C = FT<E>;
     int nmark = 0;
     (void)nmark;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int sc_ = lane & 15, sg_ = lane >> 4;             // side tile: lane = (row, k group)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c16 = lane & 15, g4 = lane >> 4;              // fragment maps: lane = (row, k group)
     // consecutive workgroup ids go round-robin to the XCDs: the members of a team share id & 7 (speed only)
     const int xg = blockIdx.x & 7, gslot = blockIdx.x >> 3;
     const int team = (gslot >> 3) * 8 + xg, member = gslot & 7;
     if (team >= A.teams) return;
+#ifdef CAPDEC_FUSED_TRACE
+    if (A.hwid && tid == 0)      // HW_ID (register 4) and XCC_ID (register 20), 32 bits each
+        A.hwid[blockIdx.x] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff);
+#endif
     const int pos_new = A.Tk - 1;
     const bool pick = A.pval != nullptr && pos_new >= 1;     // this launch also picks the previous step's tokens
     if (pick) {
@@ -389,23 +345,23 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
     float* slot0 = lds + C::OFF_W0;
     float* slot1 = lds + C::OFF_W1;
     const LaneOff lo = lane_offsets<E>(lane);
-    issue_half<E>(A.ly[0].wq, member, wave, lo, 0, slot0);
-    issue_half<E>(A.ly[0].wq, member, wave, lo, 1, slot1);
+    issue_entry<E>(A.ly[0].wq, member, wave, lo, 0, slot0);
+    issue_entry<E>(A.ly[0].wq, member, wave, lo, 1, slot1);
 
     int* meta = reinterpret_cast<int*>(lds + C::OFF_META);
-    int *s_b = meta, *s_flags = meta + 32;                  // main rows: sample (clamped), bit 0 live, bit 1 <PAD> query
-    int *ss_map = meta + 64, *ss_b = meta + 80, *ss_pos = meta + 96, *ss_act = meta + 112;   // side rows
-    int* s_ok = meta + 128;
-    int *s_tokn = meta + 144, *s_done = meta + 176;         // newest token and finished flag of the main rows
+    int *s_b = meta, *s_flags = meta + 16;                  // main rows: sample (clamped), bit 0 live, bit 1 <PAD> query
+    int *ss_map = meta + 32, *ss_b = meta + 48, *ss_pos = meta + 64, *ss_act = meta + 80;   // side rows
+    int* s_ok = meta + 96;
+    int *s_tokn = meta + 112, *s_done = meta + 128;         // newest token and finished flag of the main rows
     if (pick) {
         // the arg-max of the previous step's vocabulary projection (per-tile winners merged, lowest index on ties), as
-        // cached_advance_kernel does: four rows per wavefront, every member for all 32 rows of its team
-        // (the loads of the four rows are all issued before the first merge: one round trip, not four)
-        float pv[4][3];
-        int pi[4][3];
+        // cached_advance_kernel does: two rows per wavefront, every member for all 16 rows of its team
+        // (the loads of both rows are issued before the first merge: one round trip, not two)
+        float pv[2][3];
+        int pi[2][3];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int b = min(team * FT_ROWS + wave * 4 + q, A.B - 1);
+        for (int q = 0; q < 2; ++q) {
+            const int b = min(team * FT_ROWS + wave * 2 + q, A.B - 1);
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int n = lane + 64 * u;
@@ -415,8 +371,8 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = wave * 4 + q;
+        for (int q = 0; q < 2; ++q) {
+            const int row = wave * 2 + q;
             const int b = min(team * FT_ROWS + row, A.B - 1);
             float v = -INFINITY;
             int i = INT_MAX;
@@ -483,87 +439,99 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
 
     unsigned* tctr = A.ctr + (size_t)team * 32;
     unsigned nsig = 0;
-    const size_t tb = (size_t)team * FT_ROWS * E;           // this team's 32 x E block in the exchange buffers
+    const size_t tb = (size_t)team * FT_ROWS * E;           // this team's 16 x E block in the exchange buffers
     const size_t tsb = (size_t)team * FT_SIDE * E;          // and its 16 x E block in the side rows' buffers
-    const int blk = FT_ROWS * E * 4, sblk = FT_SIDE * E * 4;
+    constexpr int blk = 16 * E * 4;
     float* part = lds + C::OFF_PART;
     int pb = 0;
     f32x4* R = reinterpret_cast<f32x4*>(lds + C::OFF_R);
     f32x4* RS = reinterpret_cast<f32x4*>(lds + C::OFF_RS);
-    // epilogue maps: (ia, sa) for fragment-major stores (rows fastest), (ib, sb) for row-major stores (columns fastest)
-    const int ia = tid & 31, sa = tid >> 5, ib = tid >> 4, sb = tid & 15;
-    const unsigned frag_off = (unsigned)(((member * (C::NC / 4) + sa) * 32 + ia) * 16);
-    // side rows (the first 256 threads): (ja, ta) rows fastest, (jb, tb_) columns fastest
-    const int ja = tid & 15, ta = (tid >> 4) & 15, jb = (tid >> 4) & 15, tb_ = tid & 15;
-    const unsigned sfrag_off = (unsigned)(((member * (C::NC / 4) + ta) * FT_SIDE + ja) * 16);
-    const bool sthr = tid < 256;
+    // epilogue maps of the first 256 threads: (ja, ta) for fragment-major stores (rows fastest), (jb, tb_) for row-major
+    // stores (columns fastest)
+    // (recomputed from the thread id where they are used - FT_EPI_IDS - instead of living in registers across the
+    //  whole kernel: at 128 registers per lane they would be spilled, and a reload from scratch memory waits for every
+    //  store and weight load in flight)
+#define FT_EPI_IDS()                                                                                          \
+    int t_ = threadIdx.x;                                                                                     \
+    asm volatile("" : "+v"(t_));                                                                              \
+    const int ja = t_ & 15, ta = (t_ >> 4) & 15, jb = ta, tb_ = ja;                                           \
+    const unsigned frag_off = (unsigned)(((member * (C::NC / 4) + ta) * 16 + ja) * 16);                       \
+    const bool ethr = t_ < 256;                                                                               \
+    (void)jb; (void)tb_; (void)frag_off; (void)ja; (void)ta
     const int cache_bytes = A.cache_bytes;
 
-    f32x4 a[C::NA];
-    f32x4 as[C::NS];                             // (loaded and used only where the team has side rows)
+#ifdef FT_STAGGER      // timing experiment (tools/exp): the second half of the teams starts FT_STAGGER microseconds late
+    if (team >= (A.teams + 1) / 2)
+        for (int i = 0; i < FT_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
     FT_MARK();                                   // 0: set-up done
     for (int l = 0; l < A.L; ++l) {
         const capdec_fused_layer& ly = A.ly[l];
         const bool side_kv = side && l == 1;     // the side rows' layer-1 keys and values
+        const bool side_l0 = side && l == 0;     // the side rows walk layer 0 behind the attention
 
         // ---- q, k, v projections of the layer input ---------------------------------------------------------
-        if (l == 0 && pick) {
-            // the input row of the newest position: embedding of the token just picked + its position (transformer.py:126)
-            const float* er = A.emb + (int64_t)s_tokn[r] * E + wave * C::KW + 4 * h;
-            const float* pr = A.pe + (int64_t)pos_new * E + wave * C::KW + 4 * h;
-#pragma unroll
-            for (int kc = 0; kc < C::NA; ++kc)
-                a[kc] = *reinterpret_cast<const f32x4*>(er + kc * 8) + *reinterpret_cast<const f32x4*>(pr + kc * 8);
-        } else if (l == 0) {
-            const float* xr = A.x + (int64_t)s_b[r] * E + wave * C::KW + 4 * h;
-#pragma unroll
-            for (int kc = 0; kc < C::NA; ++kc) a[kc] = *reinterpret_cast<const f32x4*>(xr + kc * 8);
-        } else {
-            if (!team_wait(tctr, nsig, A.err, s_ok)) return;
-            if (wave == 0) issue_half<E>(ly.wq, member, wave, lo, 1, slot1);
-            load_frags<E, C::NA, 5>(FT_RS(A.f_z + tb, blk), wave, lane, a);
-            if (side_kv) load_frags<E, C::NS, 4>(FT_RS(A.s_z + tsb, sblk), wave, lane, as);
-            ln_frags<E, C::NA, 5>(a, A.ly[l - 1].n3g, A.ly[l - 1].n3b, part, pb, wave, lane);
-            if (side_kv) ln_frags<E, C::NS, 4>(as, A.ly[l - 1].n3g, A.ly[l - 1].n3b, part, pb, wave, lane);
-        }
-        if (wave == member) {
-#pragma unroll
-            for (int kc = 0; kc < C::NA; ++kc) R[(kc * 2 + h) * 32 + r] = a[kc];
-        }
-        FT_MARK();                               // layer input in registers
         {
-            f32x16 acc[3][C::NT];
-            f32x4 accs0[1][C::NCT];
+            f32x4 a[C::NF];
+            if (l == 0 && pick) {
+                // the input row of the newest position: embedding of the token just picked + its position (transformer.py:126)
+                const float* er = A.emb + (int64_t)s_tokn[c16] * E + wave * C::KW + 4 * g4;
+                const float* pr = A.pe + (int64_t)pos_new * E + wave * C::KW + 4 * g4;
+#pragma unroll
+                for (int kf = 0; kf < C::NF; ++kf)
+                    a[kf] = *reinterpret_cast<const f32x4*>(er + kf * 16) + *reinterpret_cast<const f32x4*>(pr + kf * 16);
+            } else if (l == 0) {
+                const float* xr = A.x + (int64_t)s_b[c16] * E + wave * C::KW + 4 * g4;
+#pragma unroll
+                for (int kf = 0; kf < C::NF; ++kf) a[kf] = *reinterpret_cast<const f32x4*>(xr + kf * 16);
+            } else {
+                if (!team_wait(tctr, nsig, A.err, s_ok)) return;
+                if (wave == 0) issue_entry<E>(ly.wq, member, wave, lo, 1, slot1);
+                load_frags<E>(FT_RS(A.f_z + tb, blk), wave, lane, a);
+                ln_frags<E>(a, A.ly[l - 1].n3g, A.ly[l - 1].n3b, part, pb, wave, lane);
+            }
+            if (wave == member) {
+#pragma unroll
+                for (int kf = 0; kf < C::NF; ++kf) R[(kf * 4 + g4) * 16 + c16] = a[kf];
+            }
+            FT_MARK();                               // layer input in registers
+            f32x4 acc[3][C::NCT];
             const float* const W3[3] = {ly.wq, ly.wk, ly.wv};
             // (with side rows the ring goes on with W_k, W_v for them before the next operation's weights)
-            gemm_stream<E, 3, 7, 0>(lds, W3, side_kv ? ly.wk : ly.wo, member, wave, lane, lo, a, acc, false, as, accs0);
+            gemm_stream<E, 3>(lds, W3, side_kv ? ly.wk : ly.wo, member, wave, lane, lo, a, acc);
             FT_MARK();                           // q, k, v contractions done
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 write_partial<E>(lds, wave, lane, acc[p]);
                 wg_barrier();
-                const float* bias = p == 0 ? ly.bq : (p == 1 ? ly.bk : ly.bv);
-                const int col = member * C::NC + sb * 4;
-                const f32x4 v = sum_partials<E>(lds, ib, sb) + *reinterpret_cast<const f32x4*>(bias + col);
-                if (p == 0) store_sc1(FT_RS(A.q + tb, blk), (unsigned)((ib * E + col) * 4), v);
-                else if (s_flags[ib] & 1)
-                    store_sc1(FT_RS(p == 1 ? ly.kc : ly.vc, cache_bytes),
-                              ((unsigned)(s_b[ib] * A.max_len + pos_new) * (unsigned)E + col) * 4u, v);
+                FT_EPI_IDS();
+                if (ethr) {
+                    const float* bias = p == 0 ? ly.bq : (p == 1 ? ly.bk : ly.bv);
+                    const int col = member * C::NC + tb_ * 4;
+                    const f32x4 v = sum_partials<E>(lds, jb, tb_) + *reinterpret_cast<const f32x4*>(bias + col);
+                    if (p == 0) store_sc1(FT_RS(A.q + tb, blk), (unsigned)((jb * E + col) * 4), v);
+                    else if (s_flags[jb] & 1)
+                        store_sc1(FT_RS(p == 1 ? ly.kc : ly.vc, cache_bytes),
+                                  ((unsigned)(s_b[jb] * A.max_len + pos_new) * (unsigned)E + col) * 4u, v);
+                }
                 wg_barrier();
             }
         }
         if (side_kv) {
-            // the side rows' layer-1 keys and values: the two weight slices once more, for the 16-row tile alone
-            issue_half<E>(ly.wk, member, wave, lo, 1, slot1);
-            f32x16 acc0[1][C::NT];
+            // the side rows' layer-1 keys and values: the two weight slices once more, for their tile
+            issue_entry<E>(ly.wk, member, wave, lo, 1, slot1);
+            f32x4 as[C::NF];
+            load_frags<E>(FT_RS(A.s_z + tsb, blk), wave, lane, as);
+            ln_frags<E>(as, A.ly[l - 1].n3g, A.ly[l - 1].n3b, part, pb, wave, lane);
             f32x4 accs[2][C::NCT];
             const float* const W2[2] = {ly.wk, ly.wv};
-            gemm_stream<E, 2, 0, 3>(lds, W2, ly.wo, member, wave, lane, lo, a, acc0, true, as, accs);
+            gemm_stream<E, 2>(lds, W2, ly.wo, member, wave, lane, lo, as, accs);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                write_partial_side<E>(lds, wave, lane, accs[p]);
+                write_partial<E>(lds, wave, lane, accs[p]);
                 wg_barrier();
-                if (sthr && ss_act[jb]) {
+                FT_EPI_IDS();
+                if (ethr && ss_act[jb]) {
                     const int col = member * C::NC + tb_ * 4;
                     const f32x4 v = sum_partials<E>(lds, jb, tb_) + *reinterpret_cast<const f32x4*>((p == 0 ? ly.bk : ly.bv) + col);
                     store_sc1(FT_RS(p == 0 ? ly.kc : ly.vc, cache_bytes), ((unsigned)ss_map[jb] * (unsigned)E + col) * 4u, v);
@@ -576,102 +544,107 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
         ++nsig;
         // (the wavefront that polls issues its part after the poll: its loads return in order, so a load in flight
         //  would hold the poll's answer back)
-        if (wave != 0) issue_half<E>(ly.wo, member, wave, lo, 1, slot1);
+        if (wave != 0) issue_entry<E>(ly.wo, member, wave, lo, 1, slot1);
         FT_MARK();                               // signalled
 
         // ---- self-attention: member = (head, half of the rows), two (row, head) pairs per wavefront -----------
         if (!team_wait(tctr, nsig, A.err, s_ok)) return;
-        if (wave == 0) issue_half<E>(ly.wo, member, wave, lo, 1, slot1);
+        if (wave == 0) issue_entry<E>(ly.wo, member, wave, lo, 1, slot1);
         FT_MARK();                               // team has q, k, v
         {
             // The two pairs of a wavefront share every instruction: lanes 0-31 serve row 2w, lanes 32-63 row 2w+1 of the
-            // member's 16 rows, both for head hd.  Scores: 4 lanes per key, 8 keys per pass and pair, kept in registers;
-            // softmax over the key lanes of the half-wavefront; context: one lane per 16 bytes of the head, the keys in
-            // turn.  The loads do not depend on one another, so queries, keys and values are in flight together.
+            // member's 8 rows (wavefronts 0-3), both for head hd.  Scores: 4 lanes per key, 8 keys per pass and pair,
+            // kept in registers; softmax over the key lanes of the half-wavefront; context: one lane per 16 bytes of the
+            // head, the keys in turn.  The loads do not depend on one another, so queries, keys and values are in flight
+            // together.
             constexpr int NM = C::DK / 16, LPV = C::DK / 4;
             static_assert(LPV == 32, "one half-wavefront per head row");
-            const int hd = member >> 1, rbase = (member & 1) * 16;
-            const int pr = lane >> 5, l32 = lane & 31;
-            const int li = 2 * wave + pr, i = rbase + li;
+            const int hd = member >> 1, rbase = (member & 1) * 8;
             float* cst = lds + C::OFF_CST;
-            const float scale = sqrtf((float)C::DK);
-            const __amdgpu_buffer_rsrc_t rs_q = FT_RS(A.q + tb, blk);
-            const __amdgpu_buffer_rsrc_t rs_k = FT_RS(ly.kc, cache_bytes);
             const __amdgpu_buffer_rsrc_t rs_v = FT_RS(ly.vc, cache_bytes);
-            const int b = s_b[i];
-            const bool pad_row = (s_flags[i] & 2) != 0;
-            const int nkeys = A.Tk;              // the newest position sees every key, <PAD> query or not
-            const unsigned kb = ((unsigned)(b * A.max_len) * (unsigned)E + (unsigned)(hd * C::DK)) * 4u;
-            const int prt = l32 & 3, kl = l32 >> 2;
-            f32x4 qreg[NM];
+            if (wave < 4) {
+                const int lf = fresh(lane);
+                const int pr = lf >> 5, l32 = lf & 31;
+                const int li = 2 * wave + pr, i = rbase + li;
+                const float scale = sqrtf((float)C::DK);
+                const __amdgpu_buffer_rsrc_t rs_q = FT_RS(A.q + tb, blk);
+                const __amdgpu_buffer_rsrc_t rs_k = FT_RS(ly.kc, cache_bytes);
+                const int b = s_b[i];
+                const bool pad_row = (s_flags[i] & 2) != 0;
+                const int nkeys = A.Tk;              // the newest position sees every key, <PAD> query or not
+                const unsigned kb = ((unsigned)(b * A.max_len) * (unsigned)E + (unsigned)(hd * C::DK)) * 4u;
+                const int prt = l32 & 3, kl = l32 >> 2;
+                f32x4 qreg[NM];
 #pragma unroll
-            for (int m = 0; m < NM; ++m) qreg[m] = load_sc1(rs_q, (unsigned)((i * E + hd * C::DK + 4 * prt + 16 * m) * 4));
-            // lane kl of pass ps holds the score of key 8*ps + kl (max_len <= 64: 8 passes)
-            float mx = -INFINITY;
-            float sreg[8];
+                for (int m = 0; m < NM; ++m) qreg[m] = load_sc1(rs_q, (unsigned)((i * E + hd * C::DK + 4 * prt + 16 * m) * 4));
+                // lane kl of pass ps holds the score of key 8*ps + kl (max_len <= 64: 8 passes)
+                float mx = -INFINITY;
+                float sreg[8];
 #pragma unroll
-            for (int ps = 0; ps < 8; ++ps) {
-                sreg[ps] = -INFINITY;
-                const int j = 8 * ps + kl;
-                if (8 * ps < nkeys) {            // uniform
-                    float d = 0.f;
-                    const int jj = j < nkeys ? j : nkeys - 1;
+                for (int ps = 0; ps < 8; ++ps) {
+                    sreg[ps] = -INFINITY;
+                    const int j = 8 * ps + kl;
+                    if (8 * ps < nkeys) {            // uniform
+                        float d = 0.f;
+                        const int jj = j < nkeys ? j : nkeys - 1;
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) {
-                        const f32x4 kk = load_sc1(rs_k, kb + (unsigned)((jj * E + 4 * prt + 16 * m) * 4));
-                        d += qreg[m][0] * kk[0] + qreg[m][1] * kk[1] + qreg[m][2] * kk[2] + qreg[m][3] * kk[3];
+                        for (int m = 0; m < NM; ++m) {
+                            const f32x4 kk = load_sc1(rs_k, kb + (unsigned)((jj * E + 4 * prt + 16 * m) * 4));
+                            d += qreg[m][0] * kk[0] + qreg[m][1] * kk[1] + qreg[m][2] * kk[2] + qreg[m][3] * kk[3];
+                        }
+                        d += __shfl_xor(d, 1, 64);
+                        d += __shfl_xor(d, 2, 64);
+                        if (j < nkeys) sreg[ps] = d / scale;
+                        mx = fmaxf(mx, sreg[ps]);
                     }
-                    d += __shfl_xor(d, 1, 64);
-                    d += __shfl_xor(d, 2, 64);
-                    if (j < nkeys) sreg[ps] = d / scale;
-                    mx = fmaxf(mx, sreg[ps]);
-                }
-            }
-#pragma unroll
-            for (int o = 4; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            float sum = 0.f;
-#pragma unroll
-            for (int ps = 0; ps < 8; ++ps) {
-                const float e = (8 * ps + kl < nkeys) ? expf(sreg[ps] - mx) : 0.f;
-                sreg[ps] = e;
-                sum += e;
-            }
-#pragma unroll
-            for (int o = 4; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
-            if (pad_row) {
-                // every score of a <PAD> query row is the same fill value: uniform over all Tk keys
-#pragma unroll
-                for (int ps = 0; ps < 8; ++ps) sreg[ps] = 1.f;
-                sum = (float)nkeys;
-            }
-            // probabilities through LDS: a wavefront-private row of 64 floats per pair
-            float* prow = lds + C::OFF_SC + wave * 128 + pr * 64;
-            if (prt == 0) {
-#pragma unroll
-                for (int ps = 0; ps < 8; ++ps)
-                    if (8 * ps + kl < nkeys) prow[8 * ps + kl] = sreg[ps] / sum;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            for (int j0 = 0; j0 < nkeys; j0 += 8) {
-                f32x4 vv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int jj = j0 + u < nkeys ? j0 + u : nkeys - 1;
-                    vv[u] = load_sc1(rs_v, kb + (unsigned)((jj * E + 4 * l32) * 4));
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (j0 + u < nkeys) o += vv[u] * prow[j0 + u];
+                for (int o = 4; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    const float e = (8 * ps + kl < nkeys) ? expf(sreg[ps] - mx) : 0.f;
+                    sreg[ps] = e;
+                    sum += e;
+                }
+#pragma unroll
+                for (int o = 4; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                if (pad_row) {
+                    // every score of a <PAD> query row is the same fill value: uniform over all Tk keys
+#pragma unroll
+                    for (int ps = 0; ps < 8; ++ps) sreg[ps] = 1.f;
+                    sum = (float)nkeys;
+                }
+                // probabilities through LDS: a wavefront-private row of 64 floats per pair
+                float* prow = lds + C::OFF_SC + wave * 128 + pr * 64;
+                if (prt == 0) {
+#pragma unroll
+                    for (int ps = 0; ps < 8; ++ps)
+                        if (8 * ps + kl < nkeys) prow[8 * ps + kl] = sreg[ps] / sum;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                for (int j0 = 0; j0 < nkeys; j0 += 8) {
+                    f32x4 vv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int jj = j0 + u < nkeys ? j0 + u : nkeys - 1;
+                        vv[u] = load_sc1(rs_v, kb + (unsigned)((jj * E + 4 * l32) * 4));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + u < nkeys) o += vv[u] * prow[j0 + u];
+                }
+                *reinterpret_cast<f32x4*>(cst + li * C::DK + 4 * l32) = o;
             }
-            *reinterpret_cast<f32x4*>(cst + li * C::CST_LD + 4 * l32) = o;
             wg_barrier();
-            {
-                const int i16 = tid & 15, sl = tid >> 4;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(cst + i16 * C::CST_LD + sl * 4);
-                store_sc1(FT_RS(A.f_ctx + tb, blk), (unsigned)(((hd * LPV + sl) * 32 + rbase + i16) * 16), v);
+            FT_EPI_IDS();
+            if (ethr) {
+                const int sl = t_ & 31, i8 = t_ >> 5;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(cst + i8 * C::DK + sl * 4);
+                store_sc1(FT_RS(A.f_ctx + tb, blk), (unsigned)(((hd * LPV + sl) * 16 + rbase + i8) * 16), v);
             }
-            if (side && l == 0 && sthr) {
+            if (side_l0 && ethr) {
                 // a <PAD> query row attends uniformly over all Tk positions: the mean of the layer's values, the newest
                 // (written by this team a moment ago) included; this member's columns of every side row
                 const int col = member * C::NC + tb_ * 4;
@@ -679,149 +652,163 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
                 const float p = 1.0f / (float)A.Tk;
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
                 for (int j = 0; j < A.Tk; ++j) o += load_sc1(rs_v, vb + (unsigned)(j * E * 4)) * p;
-                store_sc1(FT_RS(A.s_ctx + tsb, sblk), (unsigned)(((member * (C::NC / 4) + tb_) * FT_SIDE + jb) * 16), o);
+                store_sc1(FT_RS(A.s_ctx + tsb, blk), (unsigned)(((member * (C::NC / 4) + tb_) * 16 + jb) * 16), o);
             }
         }
         FT_MARK();                               // attention stored
         team_signal(tctr, member, nsig + 1);
         ++nsig;
         FT_MARK();
-        const bool side_l0 = side && l == 0;     // the side rows walk layer 0 behind the attention
 
         // ---- output projection + residual ---------------------------------------------------------------------
         if (!team_wait(tctr, nsig, A.err, s_ok)) return;
         FT_MARK();                               // team has the attention output
-        load_frags<E, C::NA, 5>(FT_RS(A.f_ctx + tb, blk), wave, lane, a);
-        if (side_l0) load_frags<E, C::NS, 4>(FT_RS(A.s_ctx + tsb, sblk), wave, lane, as);
         {
-            f32x16 acc[1][C::NT];
-            f32x4 accs[1][C::NCT];
+            f32x4 a[C::NF];
+            f32x4 acc[1][C::NCT];
             const float* const W1[1] = {ly.wo};
-            gemm_stream<E, 1, 1, 1>(lds, W1, ly.w1, member, wave, lane, lo, a, acc, side_l0, as, accs);
+            load_frags<E>(FT_RS(A.f_ctx + tb, blk), wave, lane, a);
+            gemm_stream<E, 1>(lds, W1, side_l0 ? ly.wo : ly.w1, member, wave, lane, lo, a, acc);
             FT_MARK();                           // output projection contracted
             write_partial<E>(lds, wave, lane, acc[0]);
             wg_barrier();
-            const f32x4 v = sum_partials<E>(lds, ia, sa) + *reinterpret_cast<const f32x4*>(ly.bo + member * C::NC + sa * 4) +
-                            R[sa * 32 + ia];
-            store_sc1(FT_RS(A.f_y + tb, blk), frag_off, v);
+            FT_EPI_IDS();
+            if (ethr) {
+                const f32x4 v = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.bo + member * C::NC + ta * 4) +
+                                R[ta * 16 + ja];
+                store_sc1(FT_RS(A.f_y + tb, blk), frag_off, v);
+            }
             if (side_l0) {
                 wg_barrier();
-                write_partial_side<E>(lds, wave, lane, accs[0]);
+                issue_entry<E>(ly.wo, member, wave, lo, 1, slot1);
+                load_frags<E>(FT_RS(A.s_ctx + tsb, blk), wave, lane, a);
+                gemm_stream<E, 1>(lds, W1, ly.w1, member, wave, lane, lo, a, acc);
+                write_partial<E>(lds, wave, lane, acc[0]);
                 wg_barrier();
-                if (sthr) {
+                FT_EPI_IDS();
+                if (ethr) {
                     // residual: the side row's own input, embedding + position
                     const int col = member * C::NC + ta * 4;
                     const int id = A.tok[(int64_t)ss_b[ja] * A.ldtok + ss_pos[ja]];
                     const f32x4 xin = *reinterpret_cast<const f32x4*>(A.emb + (int64_t)id * E + col) +
                                       *reinterpret_cast<const f32x4*>(A.pe + (int64_t)ss_pos[ja] * E + col);
                     const f32x4 w = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.bo + col) + xin;
-                    store_sc1(FT_RS(A.s_y + tsb, sblk), sfrag_off, w);
+                    store_sc1(FT_RS(A.s_y + tsb, blk), frag_off, w);
                 }
             }
         }
         FT_MARK();
         team_signal(tctr, member, nsig + 1);
         ++nsig;
-        if (wave != 0) issue_half<E>(ly.w1, member, wave, lo, 1, slot1);
+        if (wave != 0) issue_entry<E>(ly.w1, member, wave, lo, 1, slot1);
         FT_MARK();
 
         // ---- LayerNorm 1, + the cross-attention block (one vector per sample), LayerNorm 2, fc1 + ReLU ---------
-        f32x4 cadd[C::NA];
-        f32x4 cadds[C::NS];
         {
-            const float* cr = ly.cc + (int64_t)s_b[r] * E + wave * C::KW + 4 * h;
+            f32x4 a[C::NF];
+            f32x4 cadd[C::NF];
+            {
+                const float* cr = ly.cc + (int64_t)s_b[c16] * E + wave * C::KW + 4 * g4;
 #pragma unroll
-            for (int kc = 0; kc < C::NA; ++kc) cadd[kc] = *reinterpret_cast<const f32x4*>(cr + kc * 8);
-            if (side_l0) {
-                const float* cs = ly.cc + (int64_t)ss_b[sc_] * E + wave * C::KW + 4 * sg_;
-#pragma unroll
-                for (int kf = 0; kf < C::NS; ++kf) cadds[kf] = *reinterpret_cast<const f32x4*>(cs + kf * 16);
+                for (int kf = 0; kf < C::NF; ++kf) cadd[kf] = *reinterpret_cast<const f32x4*>(cr + kf * 16);
             }
-        }
-        if (!team_wait(tctr, nsig, A.err, s_ok)) return;
-        if (wave == 0) issue_half<E>(ly.w1, member, wave, lo, 1, slot1);
-        FT_MARK();                               // team has y
-        load_frags<E, C::NA, 5>(FT_RS(A.f_y + tb, blk), wave, lane, a);
-        if (side_l0) load_frags<E, C::NS, 4>(FT_RS(A.s_y + tsb, sblk), wave, lane, as);
-        ln_frags<E, C::NA, 5>(a, ly.n1g, ly.n1b, part, pb, wave, lane);
+            if (!team_wait(tctr, nsig, A.err, s_ok)) return;
+            if (wave == 0) issue_entry<E>(ly.w1, member, wave, lo, 1, slot1);
+            FT_MARK();                               // team has y
+            load_frags<E>(FT_RS(A.f_y + tb, blk), wave, lane, a);
+            ln_frags<E>(a, ly.n1g, ly.n1b, part, pb, wave, lane);
 #pragma unroll
-        for (int kc = 0; kc < C::NA; ++kc) a[kc] += cadd[kc];
-        ln_frags<E, C::NA, 5>(a, ly.n2g, ly.n2b, part, pb, wave, lane);
-        if (side_l0) {
-            ln_frags<E, C::NS, 4>(as, ly.n1g, ly.n1b, part, pb, wave, lane);
+            for (int kf = 0; kf < C::NF; ++kf) a[kf] += cadd[kf];
+            ln_frags<E>(a, ly.n2g, ly.n2b, part, pb, wave, lane);
+            if (wave == member) {
 #pragma unroll
-            for (int kf = 0; kf < C::NS; ++kf) as[kf] += cadds[kf];
-            ln_frags<E, C::NS, 4>(as, ly.n2g, ly.n2b, part, pb, wave, lane);
-        }
-        if (wave == member) {
-#pragma unroll
-            for (int kc = 0; kc < C::NA; ++kc) R[(kc * 2 + h) * 32 + r] = a[kc];
-            if (side_l0) {
-#pragma unroll
-                for (int kf = 0; kf < C::NS; ++kf) RS[(kf * 4 + sg_) * FT_SIDE + sc_] = as[kf];
+                for (int kf = 0; kf < C::NF; ++kf) R[(kf * 4 + g4) * 16 + c16] = a[kf];
             }
-        }
-        FT_MARK();                               // both LayerNorms done
-        {
-            f32x16 acc[1][C::NT];
-            f32x4 accs[1][C::NCT];
+            FT_MARK();                               // both LayerNorms done
+            f32x4 acc[1][C::NCT];
             const float* const W1[1] = {ly.w1};
-            gemm_stream<E, 1, 1, 1>(lds, W1, ly.w2, member, wave, lane, lo, a, acc, side_l0, as, accs);
+            gemm_stream<E, 1>(lds, W1, side_l0 ? ly.w1 : ly.w2, member, wave, lane, lo, a, acc);
             FT_MARK();
             write_partial<E>(lds, wave, lane, acc[0]);
             wg_barrier();
-            f32x4 v = sum_partials<E>(lds, ia, sa) + *reinterpret_cast<const f32x4*>(ly.b1 + member * C::NC + sa * 4);
-            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-            store_sc1(FT_RS(A.f_h + tb, blk), frag_off, v);
+            FT_EPI_IDS();
+            if (ethr) {
+                f32x4 v = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.b1 + member * C::NC + ta * 4);
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                store_sc1(FT_RS(A.f_h + tb, blk), frag_off, v);
+            }
             if (side_l0) {
                 wg_barrier();
-                write_partial_side<E>(lds, wave, lane, accs[0]);
+                issue_entry<E>(ly.w1, member, wave, lo, 1, slot1);
+                {
+                    const float* cs = ly.cc + (int64_t)ss_b[c16] * E + wave * C::KW + 4 * g4;
+#pragma unroll
+                    for (int kf = 0; kf < C::NF; ++kf) cadd[kf] = *reinterpret_cast<const f32x4*>(cs + kf * 16);
+                }
+                load_frags<E>(FT_RS(A.s_y + tsb, blk), wave, lane, a);
+                ln_frags<E>(a, ly.n1g, ly.n1b, part, pb, wave, lane);
+#pragma unroll
+                for (int kf = 0; kf < C::NF; ++kf) a[kf] += cadd[kf];
+                ln_frags<E>(a, ly.n2g, ly.n2b, part, pb, wave, lane);
+                if (wave == member) {
+#pragma unroll
+                    for (int kf = 0; kf < C::NF; ++kf) RS[(kf * 4 + g4) * 16 + c16] = a[kf];
+                }
+                gemm_stream<E, 1>(lds, W1, ly.w2, member, wave, lane, lo, a, acc);
+                write_partial<E>(lds, wave, lane, acc[0]);
                 wg_barrier();
-                if (sthr) {
+                FT_EPI_IDS();
+                if (ethr) {
                     f32x4 w = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.b1 + member * C::NC + ta * 4);
                     w[0] = fmaxf(w[0], 0.f); w[1] = fmaxf(w[1], 0.f); w[2] = fmaxf(w[2], 0.f); w[3] = fmaxf(w[3], 0.f);
-                    store_sc1(FT_RS(A.s_h + tsb, sblk), sfrag_off, w);
+                    store_sc1(FT_RS(A.s_h + tsb, blk), frag_off, w);
                 }
             }
         }
         FT_MARK();
         team_signal(tctr, member, nsig + 1);
         ++nsig;
-        if (wave != 0) issue_half<E>(ly.w2, member, wave, lo, 1, slot1);
+        if (wave != 0) issue_entry<E>(ly.w2, member, wave, lo, 1, slot1);
         FT_MARK();
 
         // ---- fc2 + residual -------------------------------------------------------------------------------------
         if (!team_wait(tctr, nsig, A.err, s_ok)) return;
-        if (wave == 0) issue_half<E>(ly.w2, member, wave, lo, 1, slot1);
+        if (wave == 0) issue_entry<E>(ly.w2, member, wave, lo, 1, slot1);
         FT_MARK();                               // team has h
-        load_frags<E, C::NA, 5>(FT_RS(A.f_h + tb, blk), wave, lane, a);
-        if (side_l0) load_frags<E, C::NS, 4>(FT_RS(A.s_h + tsb, sblk), wave, lane, as);
         {
             const float* nxt = l + 1 < A.L ? A.ly[l + 1].wq : nullptr;
-            f32x16 acc[1][C::NT];
-            f32x4 accs[1][C::NCT];
+            f32x4 a[C::NF];
+            f32x4 acc[1][C::NCT];
             const float* const W1[1] = {ly.w2};
-            gemm_stream<E, 1, 1, 1>(lds, W1, nxt, member, wave, lane, lo, a, acc, side_l0, as, accs);
+            load_frags<E>(FT_RS(A.f_h + tb, blk), wave, lane, a);
+            gemm_stream<E, 1>(lds, W1, side_l0 ? ly.w2 : nxt, member, wave, lane, lo, a, acc);
             FT_MARK();
             write_partial<E>(lds, wave, lane, acc[0]);
             wg_barrier();
-            const f32x4 v = sum_partials<E>(lds, ia, sa) + *reinterpret_cast<const f32x4*>(ly.b2 + member * C::NC + sa * 4) +
-                            R[sa * 32 + ia];
-            store_sc1(FT_RS(A.f_z + tb, blk), frag_off, v);
+            FT_EPI_IDS();
+            if (ethr) {
+                const f32x4 v = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.b2 + member * C::NC + ta * 4) +
+                                R[ta * 16 + ja];
+                store_sc1(FT_RS(A.f_z + tb, blk), frag_off, v);
+            }
             if (side_l0) {
                 wg_barrier();
-                write_partial_side<E>(lds, wave, lane, accs[0]);
+                issue_entry<E>(ly.w2, member, wave, lo, 1, slot1);
+                load_frags<E>(FT_RS(A.s_h + tsb, blk), wave, lane, a);
+                gemm_stream<E, 1>(lds, W1, nxt, member, wave, lane, lo, a, acc);
+                write_partial<E>(lds, wave, lane, acc[0]);
                 wg_barrier();
-                if (sthr) {
+                FT_EPI_IDS();
+                if (ethr) {
                     const f32x4 w = sum_partials<E>(lds, ja, ta) + *reinterpret_cast<const f32x4*>(ly.b2 + member * C::NC + ta * 4) +
-                                    RS[ta * FT_SIDE + ja];
-                    store_sc1(FT_RS(A.s_z + tsb, sblk), sfrag_off, w);
+                                    RS[ta * 16 + ja];
+                    store_sc1(FT_RS(A.s_z + tsb, blk), frag_off, w);
                 }
             }
             FT_MARK();
             team_signal(tctr, member, nsig + 1);
             ++nsig;
-            if (nxt && wave != 0) issue_half<E>(nxt, member, wave, lo, 1, slot1);
+            if (nxt && wave != 0) issue_entry<E>(nxt, member, wave, lo, 1, slot1);
             FT_MARK();
         }
     }
@@ -829,13 +816,16 @@ __global__ __launch_bounds__(FT_THREADS) void decode_layers_team_kernel(capdec_f
     // ---- LayerNorm 3 of the last layer: the rows that feed the vocabulary projection -------------------------------
     if (!team_wait(tctr, nsig, A.err, s_ok)) return;
     FT_MARK();                                   // team has the last layer's z
-    load_frags<E, C::NA, 5>(FT_RS(A.f_z + tb, blk), wave, lane, a);
-    ln_frags<E, C::NA, 5>(a, A.ly[A.L - 1].n3g, A.ly[A.L - 1].n3b, part, pb, wave, lane);
-    FT_MARK();
-    if (wave == member && (s_flags[r] & 1)) {
-        float* dst = A.x + (int64_t)s_b[r] * E + wave * C::KW + 4 * h;
+    {
+        f32x4 a[C::NF];
+        load_frags<E>(FT_RS(A.f_z + tb, blk), wave, lane, a);
+        ln_frags<E>(a, A.ly[A.L - 1].n3g, A.ly[A.L - 1].n3b, part, pb, wave, lane);
+        FT_MARK();
+        if (wave == member && (s_flags[c16] & 1)) {
+            float* dst = A.x + (int64_t)s_b[c16] * E + wave * C::KW + 4 * g4;
 #pragma unroll
-        for (int kc = 0; kc < C::NA; ++kc) *reinterpret_cast<f32x4*>(dst + kc * 8) = a[kc];
+            for (int kf = 0; kf < C::NF; ++kf) *reinterpret_cast<f32x4*>(dst + kf * 16) = a[kf];
+        }
     }
 }
 
@@ -852,7 +842,11 @@ bool capdec_fused_layers_supported(int E, int H, int L, int64_t B, int max_len) 
 int capdec_launch_fused_layers(const capdec_fused_args& a, int E, hipStream_t s) {
     CAPDEC_REQUIRE(E == 512 && a.L >= 1 && a.L <= 2);
     using C = FT<512>;
+#ifdef CAPDEC_FUSED_TRACE
+    const size_t lds_bytes = getenv("FUSED_PROBE_LDS") ? (size_t)atoi(getenv("FUSED_PROBE_LDS")) : (size_t)C::LDS_FLOATS * sizeof(float);
+#else
     constexpr size_t lds_bytes = (size_t)C::LDS_FLOATS * sizeof(float);
+#endif
     int dev = 0;
     hipError_t rc = hipGetDevice(&dev);
     if (rc != hipSuccess) return (int)rc;

@@ -47,12 +47,13 @@ int main(int argc, char** argv) {
         f.kc = dev_random((size_t)B * max_len * E, 1.f, g);
         f.vc = dev_random((size_t)B * max_len * E, 1.f, g);
     }
-    const int nteams = (B + 31) / 32;
+    const int RW = CAPDEC_FUSED_ROWS;
+    const int nteams = (B + RW - 1) / RW;
     a.L = L; a.B = B; a.max_len = max_len; a.Tk = Tk;
     a.teams = nteams;
     a.cache_bytes = (int)((size_t)B * max_len * E * 4);
     a.x = dev_random((size_t)B * E, 1.f, g);
-    const size_t TE = (size_t)nteams * 32 * E, SE = (size_t)nteams * 16 * E;
+    const size_t TE = (size_t)nteams * RW * E, SE = (size_t)nteams * 16 * E;
     a.q = dev_random(TE, 1.f, g); a.f_ctx = dev_random(TE, 1.f, g); a.f_y = dev_random(TE, 1.f, g);
     a.f_h = dev_random(TE, 1.f, g); a.f_z = dev_random(TE, 1.f, g);
     a.s_ctx = dev_random(SE, 1.f, g); a.s_y = dev_random(SE, 1.f, g); a.s_h = dev_random(SE, 1.f, g); a.s_z = dev_random(SE, 1.f, g);
@@ -60,7 +61,7 @@ int main(int argc, char** argv) {
     std::vector<int32_t> tok((size_t)B * (max_len + 1), 5), nrows(1, B), done(B, 0), plist((size_t)nteams * 16, -1);
     for (int t = 0; t < nteams; t += 4) {
         for (int k = 0; k < npad && k < 16; ++k) {
-            const int b = t * 32 + (k % 32), pos = k % (Tk > 1 ? Tk - 1 : 1);
+            const int b = t * RW + (k % RW), pos = k % (Tk > 1 ? Tk - 1 : 1);
             plist[t * 16 + k] = b * max_len + pos;
             tok[(size_t)b * (max_len + 1) + pos] = 0;
         }
@@ -79,6 +80,11 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&trace, 8 * 64 * 8));
     CK(hipMemset(trace, 0, 8 * 64 * 8));
     a.trace = trace; a.trace_team = (nteams / 2) / 4 * 4;
+    const unsigned grid = (unsigned)((nteams + 7) / 8) * 64u;
+    unsigned* hwid;
+    CK(hipMalloc(&hwid, grid * 4));
+    CK(hipMemset(hwid, 0xff, grid * 4));
+    a.hwid = hwid;
     hipStream_t s;
     CK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
@@ -101,6 +107,17 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost));
     int n = 0;
     while (n < 64 && t[n]) ++n;
+    if (getenv("FUSED_PROBE_HWID")) {
+        // which workgroups share a CU: (xcc, se, cu) of every workgroup
+        std::vector<unsigned> hw(grid);
+        CK(hipMemcpy(hw.data(), hwid, grid * 4, hipMemcpyDeviceToHost));
+        for (unsigned i = 0; i < grid; ++i) {
+            if (hw[i] == 0xffffffffu) continue;
+            const unsigned xg = i & 7, gslot = i >> 3;
+            printf("wg %4u team %3u member %u: xcc %u se %u sh %u cu %2u\n", i, (gslot >> 3) * 8 + xg, gslot & 7, hw[i] >> 16,
+                   (hw[i] >> 13) & 7, (hw[i] >> 12) & 1, (hw[i] >> 8) & 15);
+        }
+    }
     printf("stage marks of team %d (us since the member's first mark; 8 members):\n", a.trace_team);
     for (int k = 0; k < n; ++k) {
         printf("%2d:", k);
