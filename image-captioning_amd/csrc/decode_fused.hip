@@ -77,9 +77,9 @@ struct FT {
     static constexpr int OFF_R = 2 * WSLOT;           // [NC/4][16][4] own columns of the residual operand (main rows)
     static constexpr int OFF_RS = OFF_R + 16 * NC;    // [NC/4][16][4] the same of the side rows (fc2 only) ...
     static constexpr int OFF_CST = OFF_RS;            // ... and, in the attention stage, [8][DK] outputs before they are stored
-    static constexpr int OFF_PART = OFF_RS + 16 * NC; // [2][8][16] LayerNorm partial sums
-    static constexpr int OFF_SC = OFF_PART + 2 * FT_WAVES * 16;   // [4][2][64] probability rows (two (row, head) pairs per wavefront)
-    static constexpr int OFF_META = OFF_SC + 4 * 128; // ints: row descriptors, wait flag
+    static constexpr int OFF_PART = OFF_RS + 16 * NC; // [2][8][16] LayerNorm partial (mean, squared deviations) pairs
+    static constexpr int OFF_SC = OFF_PART + 4 * FT_WAVES * 16;   // [8][64] probability rows (one (row, head) pair per wavefront)
+    static constexpr int OFF_META = OFF_SC + FT_WAVES * 64;   // ints: row descriptors, wait flag
     static constexpr int LDS_FLOATS = OFF_META + 160;
     static_assert(NF == 4 && NCT == 4 && KW == NC && NC == 64 && 8 * DK == 16 * NC, "team kernel built for E = 512");
     static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
@@ -120,10 +120,12 @@ __device__ __forceinline__ void issue_entry(const float* __restrict__ W, int mem
     float* dst = slot + wave * C::WSLAB;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, E * E * 4, 0x00020000);
     const int base = ((member * C::NC + (e >> 1) * 32) * E + wave * C::KW + (e & 1) * 32) * 4;      // uniform
+#ifndef FT_EXPERIMENT_NO_DMA      // timing experiment only (tools/exp): the contractions then read whatever LDS holds
 #pragma unroll
     for (int p = 0; p < C::PIECES; ++p)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + p * 256), 16,
                                                  (p & 1) ? lo.odd : lo.even, base + p * 8 * E * 4, 0, 0);
+#endif
 }
 
 // 16 rows: lane (c, g) holds a[kq] = X[c][k0 + kq*16 + 4g + {0..3}]; MFMA m of chunk kq sums k in {kq*16 + 4g' + m};
@@ -139,8 +141,12 @@ __device__ __forceinline__ void mma_entry(const float* slot, int wave, int lane,
         for (int ct = 0; ct < 2; ++ct) {
             const int row = ct * 16 + c;
             const f32x4 b = *reinterpret_cast<const f32x4*>(img + row * 32 + ((((kq * 4 + g) ^ ((row >> 1) & 7))) << 2));
+#ifdef FT_EXPERIMENT_NO_MFMA    // timing experiment only (tools/exp)
+            acc2[ct] += b * a2[kq][0];
+#else
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kq][m], b[m], acc2[ct], 0, 0, 0);
+#endif
         }
     }
 }
@@ -178,11 +184,12 @@ __device__ __forceinline__ void gemm_stream(float* lds, const float* const (&W)[
 // this wavefront's 16 x NC partial tile into its own part of slot 1 (exactly the bytes of its entry image: no other
 // wavefront's weights are overwritten); 16-byte slots of a row XOR-swizzled by the row
 template <int E>
-__device__ __forceinline__ void write_partial(float* lds, int wave, int lane, const f32x4 (&acc)[FT<E>::NCT]) {
+__device__ __forceinline__ void write_partial(float* lds, int wave, int lane, const f32x4 (&acc)[FT<E>::NCT],
+                                              int area = FT<E>::OFF_W1) {
     using C = FT<E>;
     lane = fresh(lane);
     const int c = lane & 15, g = lane >> 4;
-    float* d = lds + C::OFF_W1 + wave * C::WSLAB;
+    float* d = lds + area + wave * C::WSLAB;
 #pragma unroll
     for (int ct = 0; ct < C::NCT; ++ct)
 #pragma unroll
@@ -192,13 +199,14 @@ __device__ __forceinline__ void write_partial(float* lds, int wave, int lane, co
         }
 }
 template <int E>
-__device__ __forceinline__ f32x4 sum_partials(const float* lds, int i, int sl) {
+__device__ __forceinline__ f32x4 sum_partials(const float* lds, int i, int sl, int area = FT<E>::OFF_W1) {
     using C = FT<E>;
-    const float* p = lds + C::OFF_W1 + i * C::NC + ((sl ^ i) << 2);
-    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    const float* p = lds + area + i * C::NC + ((sl ^ i) << 2);
+    f32x4 t[FT_WAVES];
 #pragma unroll
-    for (int w = 1; w < FT_WAVES; ++w) v += *reinterpret_cast<const f32x4*>(p + w * C::WSLAB);
-    return v;
+    for (int w = 0; w < FT_WAVES; ++w) t[w] = *reinterpret_cast<const f32x4*>(p + w * C::WSLAB);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (all eight reads in flight together, one wait)
+    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
 }
 
 // Workgroup barrier that orders LDS traffic only.  (__syncthreads() also waits for every global access of the
@@ -247,7 +255,9 @@ __device__ __forceinline__ void load_frags(__amdgpu_buffer_rsrc_t rs, int wave, 
 }
 
 // LayerNorm (eps 1e-5, affine) of 16 rows held as fragments: lane (row, g) of wavefront w holds the columns
-// w*KW + kf*16 + 4g + {0..3} of its row.  Two-pass mean / variance; the 8 wavefronts' row sums meet in LDS.
+// w*KW + kf*16 + 4g + {0..3} of its row.  Every wavefront takes the mean and the sum of squared deviations of its own
+// KW columns (two passes over registers), the 8 pairs of a row meet in LDS once and are combined exactly
+// (sum of squares about the common mean = sum of the parts' + KW * (part mean - mean)^2): one barrier per LayerNorm.
 template <int E>
 __device__ __forceinline__ void ln_frags(f32x4 (&a)[FT<E>::NF], const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* part, int& pb, int wave, int lane) {
@@ -259,36 +269,36 @@ __device__ __forceinline__ void ln_frags(f32x4 (&a)[FT<E>::NF], const float* __r
     for (int kf = 0; kf < C::NF; ++kf) s += (a[kf][0] + a[kf][1]) + (a[kf][2] + a[kf][3]);
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    float* p = part + pb * (FT_WAVES * 16);
-    pb ^= 1;
-    if (g == 0) p[wave * 16 + row] = s;
-    wg_barrier();
-    float tot = 0.f;
-#pragma unroll
-    for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 16 + row];
-    const float mean = tot / (float)E;
+    const float mw = s * (1.0f / (float)C::KW);
     float q = 0.f;
 #pragma unroll
     for (int kf = 0; kf < C::NF; ++kf) {
-        a[kf] -= mean;
-        q += (a[kf][0] * a[kf][0] + a[kf][1] * a[kf][1]) + (a[kf][2] * a[kf][2] + a[kf][3] * a[kf][3]);
+        const f32x4 d = a[kf] - mw;
+        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
     }
     q += __shfl_xor(q, 16, 64);
     q += __shfl_xor(q, 32, 64);
-    p = part + pb * (FT_WAVES * 16);
+    float2* p = reinterpret_cast<float2*>(part) + pb * (FT_WAVES * 16);
     pb ^= 1;
-    if (g == 0) p[wave * 16 + row] = q;
+    if (g == 0) p[wave * 16 + row] = make_float2(mw, q);
     wg_barrier();
-    tot = 0.f;
+    float2 t[FT_WAVES];
 #pragma unroll
-    for (int w = 0; w < FT_WAVES; ++w) tot += p[w * 16 + row];
-    const float rstd = 1.0f / sqrtf(tot / (float)E + 1e-5f);
+    for (int w = 0; w < FT_WAVES; ++w) t[w] = p[w * 16 + row];
+    float mean = 0.f;
+#pragma unroll
+    for (int w = 0; w < FT_WAVES; ++w) mean += t[w].x;
+    mean *= 1.0f / (float)FT_WAVES;
+    float m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < FT_WAVES; ++w) m2 += t[w].y + (float)C::KW * (t[w].x - mean) * (t[w].x - mean);
+    const float rstd = 1.0f / sqrtf(m2 / (float)E + 1e-5f);
     const int c0 = wave * C::KW + 4 * g;
 #pragma unroll
     for (int kf = 0; kf < C::NF; ++kf) {
         const f32x4 gg = *reinterpret_cast<const f32x4*>(gamma + c0 + kf * 16);
         const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c0 + kf * 16);
-        a[kf] = a[kf] * rstd * gg + bb;
+        a[kf] = (a[kf] - mean) * rstd * gg + bb;
     }
 }
 
@@ -460,6 +470,9 @@ void decode_layers_team_kernel(capdec_fused_args A) {
     (void)jb; (void)tb_; (void)frag_off; (void)ja; (void)ta
     const int cache_bytes = A.cache_bytes;
 
+#ifdef FT_PRIO         // timing experiment (tools/exp): the first half of the teams at a higher wavefront priority
+    if (team < (A.teams + 1) / 2) __builtin_amdgcn_s_setprio(FT_PRIO);
+#endif
 #ifdef FT_STAGGER      // timing experiment (tools/exp): the second half of the teams starts FT_STAGGER microseconds late
     if (team >= (A.teams + 1) / 2)
         for (int i = 0; i < FT_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
@@ -497,25 +510,37 @@ void decode_layers_team_kernel(capdec_fused_args A) {
             FT_MARK();                               // layer input in registers
             f32x4 acc[3][C::NCT];
             const float* const W3[3] = {ly.wq, ly.wk, ly.wv};
-            // (with side rows the ring goes on with W_k, W_v for them before the next operation's weights)
-            gemm_stream<E, 3>(lds, W3, side_kv ? ly.wk : ly.wo, member, wave, lane, lo, a, acc);
+            // (no prefetch of the next operation's weights behind this stream: both ring slots take partial tiles)
+            gemm_stream<E, 3>(lds, W3, nullptr, member, wave, lane, lo, a, acc);
             FT_MARK();                           // q, k, v contractions done
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                write_partial<E>(lds, wave, lane, acc[p]);
-                wg_barrier();
+            // q and k partial tiles side by side (slot 1, slot 0), then v: four barriers instead of six
+            write_partial<E>(lds, wave, lane, acc[0]);
+            write_partial<E>(lds, wave, lane, acc[1], C::OFF_W0);
+            wg_barrier();
+            {
                 FT_EPI_IDS();
                 if (ethr) {
-                    const float* bias = p == 0 ? ly.bq : (p == 1 ? ly.bk : ly.bv);
                     const int col = member * C::NC + tb_ * 4;
-                    const f32x4 v = sum_partials<E>(lds, jb, tb_) + *reinterpret_cast<const f32x4*>(bias + col);
-                    if (p == 0) store_sc1(FT_RS(A.q + tb, blk), (unsigned)((jb * E + col) * 4), v);
-                    else if (s_flags[jb] & 1)
-                        store_sc1(FT_RS(p == 1 ? ly.kc : ly.vc, cache_bytes),
-                                  ((unsigned)(s_b[jb] * A.max_len + pos_new) * (unsigned)E + col) * 4u, v);
+                    const f32x4 vq = sum_partials<E>(lds, jb, tb_) + *reinterpret_cast<const f32x4*>(ly.bq + col);
+                    store_sc1(FT_RS(A.q + tb, blk), (unsigned)((jb * E + col) * 4), vq);
+                    const f32x4 vk = sum_partials<E>(lds, jb, tb_, C::OFF_W0) + *reinterpret_cast<const f32x4*>(ly.bk + col);
+                    if (s_flags[jb] & 1)
+                        store_sc1(FT_RS(ly.kc, cache_bytes), ((unsigned)(s_b[jb] * A.max_len + pos_new) * (unsigned)E + col) * 4u, vk);
                 }
-                wg_barrier();
             }
+            wg_barrier();
+            issue_entry<E>(side_kv ? ly.wk : ly.wo, member, wave, lo, 0, slot0);
+            write_partial<E>(lds, wave, lane, acc[2]);
+            wg_barrier();
+            {
+                FT_EPI_IDS();
+                if (ethr && (s_flags[jb] & 1)) {
+                    const int col = member * C::NC + tb_ * 4;
+                    const f32x4 vv = sum_partials<E>(lds, jb, tb_) + *reinterpret_cast<const f32x4*>(ly.bv + col);
+                    store_sc1(FT_RS(ly.vc, cache_bytes), ((unsigned)(s_b[jb] * A.max_len + pos_new) * (unsigned)E + col) * 4u, vv);
+                }
+            }
+            wg_barrier();
         }
         if (side_kv) {
             // the side rows' layer-1 keys and values: the two weight slices once more, for their tile
@@ -547,25 +572,24 @@ void decode_layers_team_kernel(capdec_fused_args A) {
         if (wave != 0) issue_entry<E>(ly.wo, member, wave, lo, 1, slot1);
         FT_MARK();                               // signalled
 
-        // ---- self-attention: member = (head, half of the rows), two (row, head) pairs per wavefront -----------
+        // ---- self-attention: member = (head, half of the rows), one (row, head) pair per wavefront ------------
         if (!team_wait(tctr, nsig, A.err, s_ok)) return;
         if (wave == 0) issue_entry<E>(ly.wo, member, wave, lo, 1, slot1);
         FT_MARK();                               // team has q, k, v
         {
-            // The two pairs of a wavefront share every instruction: lanes 0-31 serve row 2w, lanes 32-63 row 2w+1 of the
-            // member's 8 rows (wavefronts 0-3), both for head hd.  Scores: 4 lanes per key, 8 keys per pass and pair,
-            // kept in registers; softmax over the key lanes of the half-wavefront; context: one lane per 16 bytes of the
-            // head, the keys in turn.  The loads do not depend on one another, so queries, keys and values are in flight
-            // together.
+            // One (row, head) pair per wavefront: row w of the member's 8 rows, head hd.  Scores: 4 lanes per key, 16 keys
+            // per pass, kept in registers; softmax over the key lanes; context: the two half-wavefronts take the even and
+            // the odd keys, one lane per 16 bytes of the head, and add up at the end.  Queries, the keys of the first pass
+            // and the values of the first 16 keys are in flight together.
             constexpr int NM = C::DK / 16, LPV = C::DK / 4;
             static_assert(LPV == 32, "one half-wavefront per head row");
             const int hd = member >> 1, rbase = (member & 1) * 8;
             float* cst = lds + C::OFF_CST;
             const __amdgpu_buffer_rsrc_t rs_v = FT_RS(ly.vc, cache_bytes);
-            if (wave < 4) {
+            {
                 const int lf = fresh(lane);
-                const int pr = lf >> 5, l32 = lf & 31;
-                const int li = 2 * wave + pr, i = rbase + li;
+                const int hf = lf >> 5, l32 = lf & 31;
+                const int li = wave, i = rbase + li;
                 const float scale = sqrtf((float)C::DK);
                 const __amdgpu_buffer_rsrc_t rs_q = FT_RS(A.q + tb, blk);
                 const __amdgpu_buffer_rsrc_t rs_k = FT_RS(ly.kc, cache_bytes);
@@ -573,18 +597,24 @@ void decode_layers_team_kernel(capdec_fused_args A) {
                 const bool pad_row = (s_flags[i] & 2) != 0;
                 const int nkeys = A.Tk;              // the newest position sees every key, <PAD> query or not
                 const unsigned kb = ((unsigned)(b * A.max_len) * (unsigned)E + (unsigned)(hd * C::DK)) * 4u;
-                const int prt = l32 & 3, kl = l32 >> 2;
+                const int prt = lf & 3, kl = lf >> 2;
                 f32x4 qreg[NM];
 #pragma unroll
                 for (int m = 0; m < NM; ++m) qreg[m] = load_sc1(rs_q, (unsigned)((i * E + hd * C::DK + 4 * prt + 16 * m) * 4));
-                // lane kl of pass ps holds the score of key 8*ps + kl (max_len <= 64: 8 passes)
-                float mx = -INFINITY;
-                float sreg[8];
+                f32x4 vv0[8];
 #pragma unroll
-                for (int ps = 0; ps < 8; ++ps) {
+                for (int u = 0; u < 8; ++u) {
+                    const int jj = 2 * u + hf < nkeys ? 2 * u + hf : nkeys - 1;
+                    vv0[u] = load_sc1(rs_v, kb + (unsigned)((jj * E + 4 * l32) * 4));
+                }
+                // lane kl of pass ps holds the score of key 16*ps + kl (max_len <= 64: 4 passes)
+                float mx = -INFINITY;
+                float sreg[4];
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
                     sreg[ps] = -INFINITY;
-                    const int j = 8 * ps + kl;
-                    if (8 * ps < nkeys) {            // uniform
+                    const int j = 16 * ps + kl;
+                    if (16 * ps < nkeys) {           // uniform
                         float d = 0.f;
                         const int jj = j < nkeys ? j : nkeys - 1;
 #pragma unroll
@@ -599,43 +629,50 @@ void decode_layers_team_kernel(capdec_fused_args A) {
                     }
                 }
 #pragma unroll
-                for (int o = 4; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
                 float sum = 0.f;
 #pragma unroll
-                for (int ps = 0; ps < 8; ++ps) {
-                    const float e = (8 * ps + kl < nkeys) ? expf(sreg[ps] - mx) : 0.f;
+                for (int ps = 0; ps < 4; ++ps) {
+                    const float e = (16 * ps + kl < nkeys) ? expf(sreg[ps] - mx) : 0.f;
                     sreg[ps] = e;
                     sum += e;
                 }
 #pragma unroll
-                for (int o = 4; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                for (int o = 4; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
                 if (pad_row) {
                     // every score of a <PAD> query row is the same fill value: uniform over all Tk keys
 #pragma unroll
-                    for (int ps = 0; ps < 8; ++ps) sreg[ps] = 1.f;
+                    for (int ps = 0; ps < 4; ++ps) sreg[ps] = 1.f;
                     sum = (float)nkeys;
                 }
-                // probabilities through LDS: a wavefront-private row of 64 floats per pair
-                float* prow = lds + C::OFF_SC + wave * 128 + pr * 64;
+                // probabilities through LDS: a wavefront-private row of 64 floats
+                float* prow = lds + C::OFF_SC + wave * 64;
                 if (prt == 0) {
 #pragma unroll
-                    for (int ps = 0; ps < 8; ++ps)
-                        if (8 * ps + kl < nkeys) prow[8 * ps + kl] = sreg[ps] / sum;
+                    for (int ps = 0; ps < 4; ++ps)
+                        if (16 * ps + kl < nkeys) prow[16 * ps + kl] = sreg[ps] / sum;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                for (int j0 = 0; j0 < nkeys; j0 += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (2 * u + hf < nkeys) o += vv0[u] * prow[2 * u + hf];
+                for (int j0 = 16; j0 < nkeys; j0 += 16) {
                     f32x4 vv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int jj = j0 + u < nkeys ? j0 + u : nkeys - 1;
+                        const int jj = j0 + 2 * u + hf < nkeys ? j0 + 2 * u + hf : nkeys - 1;
                         vv[u] = load_sc1(rs_v, kb + (unsigned)((jj * E + 4 * l32) * 4));
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (j0 + u < nkeys) o += vv[u] * prow[j0 + u];
+                        if (j0 + 2 * u + hf < nkeys) o += vv[u] * prow[j0 + 2 * u + hf];
                 }
-                *reinterpret_cast<f32x4*>(cst + li * C::DK + 4 * l32) = o;
+                o[0] += __shfl_xor(o[0], 32, 64);
+                o[1] += __shfl_xor(o[1], 32, 64);
+                o[2] += __shfl_xor(o[2], 32, 64);
+                o[3] += __shfl_xor(o[3], 32, 64);
+                if (hf == 0) *reinterpret_cast<f32x4*>(cst + li * C::DK + 4 * l32) = o;
             }
             wg_barrier();
             FT_EPI_IDS();
