@@ -110,6 +110,7 @@ struct capdec_fused_layer {
     const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *w1, *b1, *w2, *b2;
     const float *n1g, *n1b, *n2g, *n2b, *n3g, *n3b;
     const float* cc;          // [B][E] the cross-attention block of a single memory row, per sample
+    const float *pg, *pd, *psb;   // two memory rows (nullable): G, D [B][H][E] and sb [B][H] of the logistic closed form; cc is then c1
     float *kc, *vc;           // [B][max_len][E] self-attention cache of this layer
 };
 struct capdec_fused_args {

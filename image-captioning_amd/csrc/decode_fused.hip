@@ -302,6 +302,49 @@ __device__ __forceinline__ void ln_frags(f32x4 (&a)[FT<E>::NF], const float* __r
     }
 }
 
+// The cross-attention block over TWO memory rows in closed form, on the LayerNorm-1 output held as fragments (see
+// ln_pair_kernel in ops.hip, same arithmetic): a2 = c1 + sum_h sigmoid((x1 . G_h + sb_h) / sqrt(d_k)) D_h, added to x1.
+// G, D, c1, sb: this lane's row's sample.  The H partial dot products of a wavefront's KW columns meet in LDS once.
+template <int E>
+__device__ __forceinline__ void pair_block(f32x4 (&a)[FT<E>::NF], const float* __restrict__ G, const float* __restrict__ D,
+                                           const float* __restrict__ c1, const float* __restrict__ sb, f32x4* gp, int wave,
+                                           int lane) {
+    using C = FT<E>;
+    lane = fresh(lane);
+    const int row = lane & 15, g = lane >> 4;
+    const int c0 = wave * C::KW + 4 * g;
+    f32x4 d;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        float part = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < C::NF; ++kf) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(G + h * E + c0 + kf * 16);
+            part += (a[kf][0] * gg[0] + a[kf][1] * gg[1]) + (a[kf][2] * gg[2] + a[kf][3] * gg[3]);
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        d[h] = part;
+    }
+    if (g == 0) gp[wave * 16 + row] = d;
+    wg_barrier();
+    f32x4 t[FT_WAVES];
+#pragma unroll
+    for (int w = 0; w < FT_WAVES; ++w) t[w] = gp[w * 16 + row];
+    const f32x4 tot = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    const float scale = 1.0f / sqrtf((float)C::DK);
+    float pr[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) pr[h] = 1.0f / (1.0f + expf(-(tot[h] + sb[h]) * scale));
+#pragma unroll
+    for (int kf = 0; kf < C::NF; ++kf) {
+        f32x4 a2 = *reinterpret_cast<const f32x4*>(c1 + c0 + kf * 16);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) a2 += *reinterpret_cast<const f32x4*>(D + h * E + c0 + kf * 16) * pr[h];
+        a[kf] += a2;
+    }
+}
+
 // buffer descriptor of `bytes` bytes at p, made where it is used (four scalar registers; none stay live across stages)
 #define FT_RS(p, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, (bytes), 0x00020000)
 
@@ -754,8 +797,14 @@ void decode_layers_team_kernel(capdec_fused_args A) {
             FT_MARK();                               // team has y
             load_frags<E>(FT_RS(A.f_y + tb, blk), wave, lane, a);
             ln_frags<E>(a, ly.n1g, ly.n1b, part, pb, wave, lane);
+            if (ly.pg) {
+                // two memory rows (the gates' partial sums use the side rows' residual area: written later in this stage)
+                const int64_t bh = (int64_t)s_b[c16] * 4;
+                pair_block<E>(a, ly.pg + bh * E, ly.pd + bh * E, ly.cc + (int64_t)s_b[c16] * E, ly.psb + bh, RS, wave, lane);
+            } else {
 #pragma unroll
-            for (int kf = 0; kf < C::NF; ++kf) a[kf] += cadd[kf];
+                for (int kf = 0; kf < C::NF; ++kf) a[kf] += cadd[kf];
+            }
             ln_frags<E>(a, ly.n2g, ly.n2b, part, pb, wave, lane);
             if (wave == member) {
 #pragma unroll
@@ -784,8 +833,13 @@ void decode_layers_team_kernel(capdec_fused_args A) {
                 }
                 load_frags<E>(FT_RS(A.s_y + tsb, blk), wave, lane, a);
                 ln_frags<E>(a, ly.n1g, ly.n1b, part, pb, wave, lane);
+                if (ly.pg) {
+                    const int64_t bh = (int64_t)ss_b[c16] * 4;
+                    pair_block<E>(a, ly.pg + bh * E, ly.pd + bh * E, ly.cc + (int64_t)ss_b[c16] * E, ly.psb + bh, RS, wave, lane);
+                } else {
 #pragma unroll
-                for (int kf = 0; kf < C::NF; ++kf) a[kf] += cadd[kf];
+                    for (int kf = 0; kf < C::NF; ++kf) a[kf] += cadd[kf];
+                }
                 ln_frags<E>(a, ly.n2g, ly.n2b, part, pb, wave, lane);
                 if (wave == member) {
 #pragma unroll

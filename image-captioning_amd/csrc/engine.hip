@@ -752,7 +752,7 @@ struct DecodeWs {
     int32_t *rowmap;         // [max_len][Mcap]
     int32_t *nrows;          // [max_len + 1]
     int32_t *fin;            // [max_len] captions whose <EOS> came at step t
-    // all layers of a step in one launch (decode_fused.hip; S == 1 and a supported shape only, otherwise null)
+    // all layers of a step in one launch (decode_fused.hip; S <= 2 and a supported shape only, otherwise null)
     float *tq, *tctx, *ty, *th, *tz;    // [teams][32][E] exchange buffers of the teams
     float *sctx, *sy, *sh, *sz;         // [teams][16][E] the same of their side rows (earlier <PAD> positions)
     unsigned* ctr;           // [max_len][teams][32] arrival counters, then 32 words whose first is the error word
@@ -804,7 +804,7 @@ static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, 
     d.ctr = nullptr;
     d.pcount = d.plist = nullptr;
     d.fused_teams = 0;
-    if (S == 1 && capdec_fused_layers_supported(m->E, m->H, m->L, B, max_len)) {
+    if ((S == 1 || S == 2) && capdec_fused_layers_supported(m->E, m->H, m->L, B, max_len)) {
         d.fused_teams = (B + CAPDEC_FUSED_ROWS - 1) / CAPDEC_FUSED_ROWS;
         const size_t TE = (size_t)d.fused_teams * CAPDEC_FUSED_ROWS * m->E;
         const size_t SE = (size_t)d.fused_teams * CAPDEC_FUSED_SIDE_ROWS * m->E;
@@ -1007,8 +1007,8 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
                        out_len, out_dirty, w.rowmap, w.nrows, w.fin, B, max_len, sos, w.pcount, w.plist, w.fused_teams);
     CAPDEC_LAUNCH_CHECK();
     CAPDEC_TRY(capdec_embed_pe(w.tok, 1, ldtok, m->emb, m->pe, 0, B, 1, E, V, w.x, stream));
-    // all layers of a step in one launch (single memory row, supported shape): the arrival counters of every step start at zero
-    const bool fused = s1 && w.ctr && !(flags & CAPDEC_DECODE_NO_FUSED_LAYERS);
+    // all layers of a step in one launch (one or two memory rows, supported shape): the arrival counters of every step start at zero
+    const bool fused = (s1 || s2) && w.ctr && !(flags & CAPDEC_DECODE_NO_FUSED_LAYERS);
     const size_t ctr_step = (size_t)w.fused_teams * 32;
     unsigned* fuse_err = fused ? w.ctr + (size_t)max_len * ctr_step : nullptr;
     if (fused) CAPDEC_TRY((int)hipMemsetAsync(w.ctr, 0, ((size_t)max_len * ctr_step + 32) * sizeof(unsigned), s));
@@ -1043,6 +1043,11 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
                 f.w1 = ly.ff_w1; f.b1 = ly.ff_b1; f.w2 = ly.ff_w2; f.b2 = ly.ff_b2;
                 f.n1g = ly.n1_g; f.n1b = ly.n1_b; f.n2g = ly.n2_g; f.n2b = ly.n2_b; f.n3g = ly.n3_g; f.n3b = ly.n3_b;
                 f.cc = w.cc + l * BE;
+                if (s2) {
+                    f.pg = w.pg + (size_t)l * BE * H;
+                    f.pd = w.pd + (size_t)l * BE * H;
+                    f.psb = w.psb + (size_t)l * B * H;
+                }
                 f.kc = w.kc + (size_t)l * BE * max_len;
                 f.vc = w.vc + (size_t)l * BE * max_len;
             }

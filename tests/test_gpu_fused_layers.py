@@ -54,6 +54,27 @@ def test_one_launch_layers_follow_generated_pad_tokens(L, B):
         assert sum(R.PAD in row[:-2] for row in fused) >= (2 if B < 64 else 4), [row for row in fused][:4]
 
 
+@pytest.mark.parametrize("L,B", [(2, 70), (1, 20)])
+def test_one_launch_layers_with_two_memory_rows(L, B):
+    """Two memory rows (the ViT+CNN and YOLO+CNN heads): the logistic closed form of the cross-attention block inside the
+    one-launch layers, main rows and <PAD> side rows alike, against the launch-per-operation form, the general
+    cross-attention kernels and the oracle."""
+    V, ML = 2000, 12
+    dec = _decoder(L, V, 50 + L, pad_bias=1.2)
+    g = torch.Generator().manual_seed(B + 1)
+    enc = torch.randn(B, 2, E, generator=g)
+    fused, nd = _ids(dec, enc, ML)
+    plain, _ = _ids(dec, enc, ML, fused_layers=False)
+    general, _ = _ids(dec, enc, ML, no_s1_shortcut=True)
+    sd = cpu_sd(dec)
+    ties = check_greedy(fused, sd, enc, H, ML)
+    check_greedy(plain, sd, enc, H, ML)
+    assert sum(a == b for a, b in zip(fused, plain)) >= B - max(1, ties)
+    assert sum(a == b for a, b in zip(fused, general)) >= B - max(1, ties)
+    if L == 2:
+        assert sum(R.PAD in row[:-2] for row in fused) >= 2
+
+
 def test_one_launch_layers_rows_of_the_last_step_and_bit_identical_runs():
     """The rows handed to the vocabulary projection agree with the launch-per-operation form to rounding, and two runs
     agree bit for bit (fixed summation orders, no float atomics)."""
