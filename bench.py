@@ -545,6 +545,11 @@ def variants_bench(device, steps=6, warmup=2):
     _, dt_b = timed(lambda: model.caption_ids_beam(feats_h, beam_width=3, max_length=LEN), 3)
     out["beam_w3"] = {"workload": f"cfg2 CNN-Attn beam search, width 3, S=1, B={B}, len {LEN} (KV caches re-gathered by parent)",
                       "value": B / dt_b, "unit": "captions/s", "ms_per_step": dt_b * 1e3}
+    # the same search at the reference's evaluation batch size (eval.py:91-102 draws batches of 64): here the decoder
+    # layers of a step run as one launch inside the cached search
+    _, dt_b64 = timed(lambda: model.caption_ids_beam(feats_h[:64], beam_width=3, max_length=LEN), 5)
+    out["beam_w3_b64"] = {"workload": f"cfg2 CNN-Attn beam search, width 3, S=1, B=64, len {LEN}",
+                          "value": 64 / dt_b64, "unit": "captions/s", "ms_per_step": dt_b64 * 1e3}
     del feats_h
     # ---- serving-style pipelining of the headline workload: two host threads, each with its own HIP stream, each
     #      running whole B=1024 steps (head + cached greedy decode + ids to the host).  One batch's launch latencies and

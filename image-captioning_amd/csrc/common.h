@@ -118,6 +118,7 @@ struct capdec_fused_args {
     int L, B, max_len, Tk;    // Tk = keys of this step (step index + 1)
     int teams;                // ceil(B / CAPDEC_FUSED_ROWS)
     int cache_bytes;          // B * max_len * E * 4
+    int cc_div;               // row b uses the cross-attention constants of sample b / cc_div (beam search: the width)
     float* x;                 // [B][E] row-major: the step's input rows; receives the last LayerNorm's rows
     float* q;                 // [teams][32][E] row-major queries
     float *f_ctx, *f_y, *f_h, *f_z;   // [teams][E/4][32][4] fragment-major exchange buffers

@@ -217,13 +217,19 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // finished operation.  Publishing: every storing wavefront drains its stores, the workgroup meets, one lane stores the
 // flag write-through.  (An atomic add on a shared counter costs its issuer about 3.5 us until it is acknowledged.)
 __device__ __forceinline__ void team_signal(unsigned* flags, int member, unsigned epoch) {
+#ifndef FT_EXPERIMENT_NO_WAIT     // timing experiment only (tools/exp): results are garbage
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     wg_barrier();
     if (threadIdx.x == 0) __hip_atomic_store(flags + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Lanes 0..7 of the first wavefront poll the eight flags (relaxed, L1-bypassing), the workgroup meets behind them;
 // false (for every thread) when the spin ran out.
 __device__ __forceinline__ bool team_wait(unsigned* flags, unsigned epoch, unsigned* err, int* flag) {
+#ifdef FT_EXPERIMENT_NO_WAIT
+    wg_barrier();
+    return true;
+#endif
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         unsigned spins = 0;
@@ -788,7 +794,7 @@ void decode_layers_team_kernel(capdec_fused_args A) {
             f32x4 a[C::NF];
             f32x4 cadd[C::NF];
             {
-                const float* cr = ly.cc + (int64_t)s_b[c16] * E + wave * C::KW + 4 * g4;
+                const float* cr = ly.cc + (int64_t)(s_b[c16] / A.cc_div) * E + wave * C::KW + 4 * g4;
 #pragma unroll
                 for (int kf = 0; kf < C::NF; ++kf) cadd[kf] = *reinterpret_cast<const f32x4*>(cr + kf * 16);
             }
@@ -799,8 +805,8 @@ void decode_layers_team_kernel(capdec_fused_args A) {
             ln_frags<E>(a, ly.n1g, ly.n1b, part, pb, wave, lane);
             if (ly.pg) {
                 // two memory rows (the gates' partial sums use the side rows' residual area: written later in this stage)
-                const int64_t bh = (int64_t)s_b[c16] * 4;
-                pair_block<E>(a, ly.pg + bh * E, ly.pd + bh * E, ly.cc + (int64_t)s_b[c16] * E, ly.psb + bh, RS, wave, lane);
+                const int64_t bs = s_b[c16] / A.cc_div, bh = bs * 4;
+                pair_block<E>(a, ly.pg + bh * E, ly.pd + bh * E, ly.cc + bs * E, ly.psb + bh, RS, wave, lane);
             } else {
 #pragma unroll
                 for (int kf = 0; kf < C::NF; ++kf) a[kf] += cadd[kf];
@@ -827,15 +833,15 @@ void decode_layers_team_kernel(capdec_fused_args A) {
                 wg_barrier();
                 issue_entry<E>(ly.w1, member, wave, lo, 1, slot1);
                 {
-                    const float* cs = ly.cc + (int64_t)ss_b[c16] * E + wave * C::KW + 4 * g4;
+                    const float* cs = ly.cc + (int64_t)(ss_b[c16] / A.cc_div) * E + wave * C::KW + 4 * g4;
 #pragma unroll
                     for (int kf = 0; kf < C::NF; ++kf) cadd[kf] = *reinterpret_cast<const f32x4*>(cs + kf * 16);
                 }
                 load_frags<E>(FT_RS(A.s_y + tsb, blk), wave, lane, a);
                 ln_frags<E>(a, ly.n1g, ly.n1b, part, pb, wave, lane);
                 if (ly.pg) {
-                    const int64_t bh = (int64_t)ss_b[c16] * 4;
-                    pair_block<E>(a, ly.pg + bh * E, ly.pd + bh * E, ly.cc + (int64_t)ss_b[c16] * E, ly.psb + bh, RS, wave, lane);
+                    const int64_t bs = ss_b[c16] / A.cc_div, bh = bs * 4;
+                    pair_block<E>(a, ly.pg + bh * E, ly.pd + bh * E, ly.cc + bs * E, ly.psb + bh, RS, wave, lane);
                 } else {
 #pragma unroll
                     for (int kf = 0; kf < C::NF; ++kf) a[kf] += cadd[kf];
@@ -931,7 +937,7 @@ bool capdec_fused_layers_supported(int E, int H, int L, int64_t B, int max_len) 
 }
 
 int capdec_launch_fused_layers(const capdec_fused_args& a, int E, hipStream_t s) {
-    CAPDEC_REQUIRE(E == 512 && a.L >= 1 && a.L <= 2);
+    CAPDEC_REQUIRE(E == 512 && a.L >= 1 && a.L <= 2 && a.cc_div >= 1);
     using C = FT<512>;
 #ifdef CAPDEC_FUSED_TRACE
     const size_t lds_bytes = getenv("FUSED_PROBE_LDS") ? (size_t)atoi(getenv("FUSED_PROBE_LDS")) : (size_t)C::LDS_FLOATS * sizeof(float);

@@ -1054,6 +1054,7 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
             fa.L = L; fa.B = B; fa.max_len = max_len; fa.Tk = t + 1;
             fa.teams = w.fused_teams;
             fa.cache_bytes = (int)(BE * max_len * sizeof(float));
+            fa.cc_div = 1;
             fa.x = w.x; fa.q = w.tq; fa.f_ctx = w.tctx; fa.f_y = w.ty; fa.f_h = w.th; fa.f_z = w.tz;
             fa.s_ctx = w.sctx; fa.s_y = w.sy; fa.s_h = w.sh; fa.s_z = w.sz;
             fa.tok = w.tok; fa.ldtok = ldtok; fa.nrows = rows; fa.done = w.done;
@@ -1439,8 +1440,30 @@ struct TfBeamCacheWs {
     float *cc, *ck, *cv, *encx;
     float *pg, *pd, *psb;                     // S == 2: G, D [L][B][H][E] and sb [L][B][H] of the two-row closed form
     float* cache[2];                          // each [L][2][N][max_len][E]
+    // all layers of a step in one launch (decode_fused.hip; S <= 2 and a supported shape, otherwise null): exchange
+    // blocks, the hand-off flags of every step, and what that kernel reads of a greedy decode's state - a row count, the
+    // finished flags (all zero here) and the <PAD> lists (all free here: such samples are redone, see above)
+    float *tq, *tctx, *ty, *th, *tz;
+    unsigned* ctr;
+    int32_t *fz_nrows, *fz_done, *fz_plist;
+    int fused_teams;
     BeamBufs b;
 };
+
+CAPDEC_HOOK_VAR(g_beam_no_fused);          // tuning build: 1 keeps the launch-per-operation layers
+
+__global__ void beam_fused_init_kernel(int32_t* __restrict__ nrows, int32_t* __restrict__ done, int32_t* __restrict__ plist,
+                                       int N, int nlist) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (g == 0) nrows[0] = N;
+    for (int i = g; i < N; i += nth) done[i] = 0;
+    for (int i = g; i < nlist; i += nth) plist[i] = -1;
+}
+// a wait of the one-launch layers that ran out: every sample is reported for the full-prefix form
+__global__ void beam_fused_err_kernel(const unsigned* __restrict__ err, int32_t* __restrict__ pad_seen, int B) {
+    if (err[0] == 0) return;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) pad_seen[b] = 1;
+}
 
 static size_t carve_tf_beam_cached(const capdec_tf_model* m, int B, int W, int S, int max_len, void* base,
                                    TfBeamCacheWs* w) {
@@ -1461,6 +1484,20 @@ static size_t carve_tf_beam_cached(const capdec_tf_model* m, int B, int W, int S
     d.pd = c.take<float>(S == 2 ? (size_t)m->L * BE * m->H : 1);
     d.psb = c.take<float>(S == 2 ? (size_t)m->L * B * m->H : 1);
     for (int n = 0; n < 2; ++n) d.cache[n] = c.take<float>((size_t)m->L * 2 * NE * max_len);
+    d.tq = d.tctx = d.ty = d.th = d.tz = nullptr;
+    d.ctr = nullptr;
+    d.fz_nrows = d.fz_done = d.fz_plist = nullptr;
+    d.fused_teams = 0;
+    if (S <= 2 && capdec_fused_layers_supported(m->E, m->H, m->L, N, max_len)) {
+        d.fused_teams = (N + CAPDEC_FUSED_ROWS - 1) / CAPDEC_FUSED_ROWS;
+        const size_t TE = (size_t)d.fused_teams * CAPDEC_FUSED_ROWS * m->E;
+        d.tq = c.take<float>(TE); d.tctx = c.take<float>(TE); d.ty = c.take<float>(TE);
+        d.th = c.take<float>(TE); d.tz = c.take<float>(TE);
+        d.ctr = c.take<unsigned>(((size_t)max_len * d.fused_teams + 1) * 32);
+        d.fz_nrows = c.take<int32_t>(4);
+        d.fz_done = c.take<int32_t>((size_t)N);
+        d.fz_plist = c.take<int32_t>((size_t)d.fused_teams * CAPDEC_FUSED_SIDE_ROWS);
+    }
     carve_beam_bufs(c, N, W, m->V, max_len, &d.b);
     if (w) *w = d;
     return c.off;
@@ -1489,9 +1526,18 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
     const size_t NE = (size_t)N * E, BE = (size_t)B * E;
     const int64_t ldtok = max_len + 1, cstride = (int64_t)max_len * E;
     const bool s1 = S == 1, s2 = S == 2;
+    const bool fused = w.ctr && !g_beam_no_fused;
+    const size_t ctr_step = (size_t)w.fused_teams * 32;
+    unsigned* fuse_err = fused ? w.ctr + (size_t)max_len * ctr_step : nullptr;
     if (t_begin == 0) {
         hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, w.b.st[0], ldtok, N, sos, w.b.unfinished, max_len);
         CAPDEC_LAUNCH_CHECK();
+        if (fused) {
+            CAPDEC_TRY((int)hipMemsetAsync(w.ctr, 0, ((size_t)max_len * ctr_step + 32) * sizeof(unsigned), s));
+            hipLaunchKernelGGL(beam_fused_init_kernel, dim3(64), dim3(256), 0, s, w.fz_nrows, w.fz_done, w.fz_plist, N,
+                               w.fused_teams * CAPDEC_FUSED_SIDE_ROWS);
+            CAPDEC_LAUNCH_CHECK();
+        }
         if (hipMemsetAsync(pad_seen, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return (int)hipGetLastError();
         if (s1) {
             for (int l = 0; l < L; ++l) {
@@ -1515,7 +1561,37 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
     for (int t = t_begin; t < t_end; ++t) {
         float* cur = w.cache[t & 1];
         float* nxt = w.cache[(t + 1) & 1];
-        for (int l = 0; l < L; ++l) {
+        if (fused) {
+            // every layer of the step as one launch over the N hypothesis rows (row n: the constants of sample n / W)
+            capdec_fused_args fa{};
+            for (int l = 0; l < L; ++l) {
+                const capdec_tf_layer& ly = m->layers[l];
+                capdec_fused_layer& f = fa.ly[l];
+                f.wq = ly.self_attn.wq; f.bq = ly.self_attn.bq; f.wk = ly.self_attn.wk; f.bk = ly.self_attn.bk;
+                f.wv = ly.self_attn.wv; f.bv = ly.self_attn.bv; f.wo = ly.self_attn.wo; f.bo = ly.self_attn.bo;
+                f.w1 = ly.ff_w1; f.b1 = ly.ff_b1; f.w2 = ly.ff_w2; f.b2 = ly.ff_b2;
+                f.n1g = ly.n1_g; f.n1b = ly.n1_b; f.n2g = ly.n2_g; f.n2b = ly.n2_b; f.n3g = ly.n3_g; f.n3b = ly.n3_b;
+                f.cc = w.cc + l * BE;
+                if (s2) {
+                    f.pg = w.pg + (size_t)l * BE * H;
+                    f.pd = w.pd + (size_t)l * BE * H;
+                    f.psb = w.psb + (size_t)l * B * H;
+                }
+                f.kc = cur + (size_t)(2 * l) * NE * max_len;
+                f.vc = cur + (size_t)(2 * l + 1) * NE * max_len;
+            }
+            fa.L = L; fa.B = N; fa.max_len = max_len; fa.Tk = t + 1;
+            fa.teams = w.fused_teams;
+            fa.cache_bytes = (int)(NE * max_len * sizeof(float));
+            fa.cc_div = W;
+            fa.x = w.x; fa.q = w.tq; fa.f_ctx = w.tctx; fa.f_y = w.ty; fa.f_h = w.th; fa.f_z = w.tz;
+            fa.s_ctx = w.tctx; fa.s_y = w.ty; fa.s_h = w.th; fa.s_z = w.tz;      // (no side rows: never touched)
+            fa.tok = w.b.st[t & 1].tok; fa.ldtok = ldtok; fa.nrows = w.fz_nrows; fa.done = w.fz_done;
+            fa.plist = w.fz_plist; fa.emb = m->emb; fa.pe = m->pe;
+            fa.ctr = w.ctr + (size_t)t * ctr_step; fa.err = fuse_err;
+            CAPDEC_TRY(capdec_launch_fused_layers(fa, E, s));
+        }
+        for (int l = 0; l < L && !fused; ++l) {
             const capdec_tf_layer& ly = m->layers[l];
             float* kc = cur + (size_t)(2 * l) * NE * max_len;
             float* vc = cur + (size_t)(2 * l + 1) * NE * max_len;
@@ -1566,8 +1642,19 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
     hipLaunchKernelGGL(beam_result_kernel, dim3((B + 63) / 64), dim3(64), 0, s, w.b.st[t_end & 1], ldtok, B, W, t_end,
                        max_len, eos, out_ids, out_len, out_scores, w.b.unfinished, n_unfinished);
     CAPDEC_LAUNCH_CHECK();
+    if (fused) {
+        hipLaunchKernelGGL(beam_fused_err_kernel, dim3(16), dim3(256), 0, s, fuse_err, pad_seen, B);
+        CAPDEC_LAUNCH_CHECK();
+    }
     return 0;
 }
+
+#ifdef CAPDEC_TUNING_HOOKS
+int capdec_beam_force_unfused(int on) {
+    g_beam_no_fused = on ? 1 : 0;
+    return 0;
+}
+#endif
 
 struct RnnBeamWs {
     float *x, *h[2], *c[2];

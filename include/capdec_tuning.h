@@ -3,7 +3,7 @@
  *
  * The product library libcapdec.so is compiled without them: there the choices below are compile-time constants and
  * the library keeps no state between calls.  The tuning build is the same sources compiled with
- * -DCAPDEC_TUNING_HOOKS; it exports everything capdec.h declares plus these five process-wide switches, which the
+ * -DCAPDEC_TUNING_HOOKS; it exports everything capdec.h declares plus these six process-wide switches, which the
  * tests use to run one input through two kernel variants (and compare them bit for bit) and the benchmark tools use to
  * time tile shapes.  They have no counterpart in the reference.  Not thread-safe; never link this build into a server.
  */
@@ -29,6 +29,9 @@ int capdec_attention_bwd_force_two_pass(int on);
 /* non-zero: long unmasked memories (more than 64 keys) stay on the one-wavefront-per-row forward kernel instead of the
  * chunked one */
 int capdec_attention_force_row_kernel(int on);
+/* non-zero: the KV-cached beam search keeps a step's decoder layers as separate launches (shapes that the one-launch
+ * layers of the greedy decoder support normally take those) */
+int capdec_beam_force_unfused(int on);
 
 #ifdef __cplusplus
 }

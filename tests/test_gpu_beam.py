@@ -126,6 +126,26 @@ def test_cached_beam_equals_full_prefix_beam_at_batch_256():
         close(a[2][same], b[2][same], rtol=1e-4, atol=1e-4, what="scores")
 
 
+@pytest.mark.parametrize("S,W,B", [(1, 3, 100), (2, 2, 37), (1, 4, 16)])
+def test_cached_beam_one_launch_layers_against_separate_launches(S, W, B):
+    """Shapes the one-launch decoder layers support (E=512, H=4, L<=2, one or two memory rows) take them inside the
+    KV-cached beam search; the tuning build can keep the launch-per-operation layers: same hypotheses and scores."""
+    from capdec import _lib
+    from gpu_util import plain_decoder
+    torch.manual_seed(5)
+    dec = plain_decoder(512, 3000, 4, 2).cuda().eval()
+    g = torch.Generator().manual_seed(79 + S)
+    enc = torch.randn(B, S, 512, generator=g).cuda()
+    with _lib.tuning_build() as lib:
+        a = dec.beam_ids(enc, R.SOS, R.EOS, W, 15, return_scores=True)
+        lib.capdec_beam_force_unfused(1)
+        b = dec.beam_ids(enc, R.SOS, R.EOS, W, 15, return_scores=True)
+    ra, rb = _rows(a[0], a[1]), _rows(b[0], b[1])
+    assert sum(x != y for x, y in zip(ra, rb)) <= 1
+    same = [i for i, (x, y) in enumerate(zip(ra, rb)) if x == y]
+    close(a[2][same], b[2][same], rtol=1e-4, atol=1e-4, what="scores")
+
+
 def _peaked_sd(fx, prefix, scale, eos_bias):
     sd = sub_sd(fx, prefix)
     sd["fc2.weight"] = sd["fc2.weight"] * float(scale)

@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
     a.L = L; a.B = B; a.max_len = max_len; a.Tk = Tk;
     a.teams = nteams;
     a.cache_bytes = (int)((size_t)B * max_len * E * 4);
+    a.cc_div = 1;
     a.x = dev_random((size_t)B * E, 1.f, g);
     const size_t TE = (size_t)nteams * RW * E, SE = (size_t)nteams * 16 * E;
     a.q = dev_random(TE, 1.f, g); a.f_ctx = dev_random(TE, 1.f, g); a.f_y = dev_random(TE, 1.f, g);
