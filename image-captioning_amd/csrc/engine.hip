@@ -1432,9 +1432,11 @@ int capdec_tf_beam_search(const capdec_tf_model* m, const float* enc, int B, int
 }
 
 // ---- KV-cached beam search: one new position per hypothesis and step; the caches are re-gathered after every
-// selection so that each surviving hypothesis owns its parent's keys and values.  Samples in which a <PAD> token is
-// generated are reported in pad_seen: the reference lets a <PAD> query row attend uniformly over the CURRENT length,
-// which changes that position's output at every later step, so those samples must be redone with the full-prefix form.
+// selection so that each surviving hypothesis owns its parent's keys and values.  The reference lets a <PAD> query row
+// attend uniformly over the CURRENT length, which changes that position's output at every later step.  Where the
+// one-launch layers run (decode_fused.hip) the <PAD> positions of a hypothesis' prefix follow along as side rows and
+// only a team with more of them than side rows reports its samples in pad_seen; the launch-per-operation layers report
+// every sample in which a <PAD> token is generated.  Reported samples must be redone with the full-prefix form.
 struct TfBeamCacheWs {
     float *x, *y, *x2, *x1, *q, *ao, *hb;     // [N][E]
     float *cc, *ck, *cv, *encx;
@@ -1442,8 +1444,8 @@ struct TfBeamCacheWs {
     float* cache[2];                          // each [L][2][N][max_len][E]
     // all layers of a step in one launch (decode_fused.hip; S <= 2 and a supported shape, otherwise null): exchange
     // blocks, the hand-off flags of every step, and what that kernel reads of a greedy decode's state - a row count, the
-    // finished flags (all zero here) and the <PAD> lists (all free here: such samples are redone, see above)
-    float *tq, *tctx, *ty, *th, *tz;
+    // finished flags (all zero here) and the <PAD> lists (rebuilt every step from the hypotheses' prefixes)
+    float *tq, *tctx, *ty, *th, *tz, *sctx, *sy, *sh, *sz;
     unsigned* ctr;
     int32_t *fz_nrows, *fz_done, *fz_plist;
     int fused_teams;
@@ -1458,6 +1460,40 @@ __global__ void beam_fused_init_kernel(int32_t* __restrict__ nrows, int32_t* __r
     if (g == 0) nrows[0] = N;
     for (int i = g; i < N; i += nth) done[i] = 0;
     for (int i = g; i < nlist; i += nth) plist[i] = -1;
+}
+// The <PAD> positions in the prefixes of a team's 16 hypothesis rows, for the side rows of the one-launch layers (which
+// refresh those positions' layer-1 keys and values for the current length: the reference lets a <PAD> query row attend
+// uniformly over all positions so far).  Rebuilt every step, because the selection permutes the hypotheses.  One
+// wavefront per team; row r's entries follow those of the rows before it; a team with more than 16 such positions
+// reports the samples of the rows that did not fit (pad_seen: redone with the full-prefix form).
+__global__ __launch_bounds__(64) void beam_plist_kernel(const int32_t* __restrict__ tok, int64_t ldtok, int N, int t,
+                                                        int max_len, int W, int32_t* __restrict__ plist,
+                                                        int32_t* __restrict__ pad_seen) {
+    const int team = blockIdx.x, lane = threadIdx.x;
+    const int n = team * CAPDEC_FUSED_ROWS + (lane & 15);
+    const bool act = lane < CAPDEC_FUSED_ROWS && n < N;
+    int cnt = 0;
+    if (act)
+        for (int p = 1; p < t; ++p) cnt += tok[(int64_t)n * ldtok + p] == 0;
+    int off = cnt;                                   // inclusive prefix sum over the 16 rows
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const int o = __shfl_up(off, d, 64);
+        if ((lane & 15) >= d) off += o;
+    }
+    off -= cnt;
+    int32_t* pl = plist + (size_t)team * CAPDEC_FUSED_SIDE_ROWS;
+    if (lane < CAPDEC_FUSED_SIDE_ROWS) pl[lane] = -1;
+    __syncthreads();
+    if (act && cnt) {
+        int k = off;
+        for (int p = 1; p < t; ++p)
+            if (tok[(int64_t)n * ldtok + p] == 0) {
+                if (k < CAPDEC_FUSED_SIDE_ROWS) pl[k] = n * max_len + p;
+                else pad_seen[n / W] = 1;
+                ++k;
+            }
+    }
 }
 // a wait of the one-launch layers that ran out: every sample is reported for the full-prefix form
 __global__ void beam_fused_err_kernel(const unsigned* __restrict__ err, int32_t* __restrict__ pad_seen, int B) {
@@ -1484,7 +1520,7 @@ static size_t carve_tf_beam_cached(const capdec_tf_model* m, int B, int W, int S
     d.pd = c.take<float>(S == 2 ? (size_t)m->L * BE * m->H : 1);
     d.psb = c.take<float>(S == 2 ? (size_t)m->L * B * m->H : 1);
     for (int n = 0; n < 2; ++n) d.cache[n] = c.take<float>((size_t)m->L * 2 * NE * max_len);
-    d.tq = d.tctx = d.ty = d.th = d.tz = nullptr;
+    d.tq = d.tctx = d.ty = d.th = d.tz = d.sctx = d.sy = d.sh = d.sz = nullptr;
     d.ctr = nullptr;
     d.fz_nrows = d.fz_done = d.fz_plist = nullptr;
     d.fused_teams = 0;
@@ -1493,6 +1529,8 @@ static size_t carve_tf_beam_cached(const capdec_tf_model* m, int B, int W, int S
         const size_t TE = (size_t)d.fused_teams * CAPDEC_FUSED_ROWS * m->E;
         d.tq = c.take<float>(TE); d.tctx = c.take<float>(TE); d.ty = c.take<float>(TE);
         d.th = c.take<float>(TE); d.tz = c.take<float>(TE);
+        const size_t SE = (size_t)d.fused_teams * CAPDEC_FUSED_SIDE_ROWS * m->E;
+        d.sctx = c.take<float>(SE); d.sy = c.take<float>(SE); d.sh = c.take<float>(SE); d.sz = c.take<float>(SE);
         d.ctr = c.take<unsigned>(((size_t)max_len * d.fused_teams + 1) * 32);
         d.fz_nrows = c.take<int32_t>(4);
         d.fz_done = c.take<int32_t>((size_t)N);
@@ -1585,10 +1623,15 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
             fa.cache_bytes = (int)(NE * max_len * sizeof(float));
             fa.cc_div = W;
             fa.x = w.x; fa.q = w.tq; fa.f_ctx = w.tctx; fa.f_y = w.ty; fa.f_h = w.th; fa.f_z = w.tz;
-            fa.s_ctx = w.tctx; fa.s_y = w.ty; fa.s_h = w.th; fa.s_z = w.tz;      // (no side rows: never touched)
+            fa.s_ctx = w.sctx; fa.s_y = w.sy; fa.s_h = w.sh; fa.s_z = w.sz;
             fa.tok = w.b.st[t & 1].tok; fa.ldtok = ldtok; fa.nrows = w.fz_nrows; fa.done = w.fz_done;
             fa.plist = w.fz_plist; fa.emb = m->emb; fa.pe = m->pe;
             fa.ctr = w.ctr + (size_t)t * ctr_step; fa.err = fuse_err;
+            if (L >= 2 && t >= 2) {
+                hipLaunchKernelGGL(beam_plist_kernel, dim3(w.fused_teams), dim3(64), 0, s, w.b.st[t & 1].tok, ldtok, N, t,
+                                   max_len, W, w.fz_plist, pad_seen);
+                CAPDEC_LAUNCH_CHECK();
+            }
             CAPDEC_TRY(capdec_launch_fused_layers(fa, E, s));
         }
         for (int l = 0; l < L && !fused; ++l) {
@@ -1629,7 +1672,8 @@ int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int
             CAPDEC_TRY(capdec_launch_layernorm_rows(w.y, nullptr, 1, nullptr, ly.n3_g, ly.n3_b, 1e-5f, N, E, w.x, nullptr, s));
         }
         CAPDEC_TRY(linear(w.x, E, N, m->fc2_w, m->fc2_b, V, E, w.b.logits, V, nullptr, 0, 0, s));
-        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, s, pad_seen));
+        // (with the one-launch layers a <PAD> hypothesis is followed by side rows, not reported)
+        CAPDEC_TRY(beam_pick(w.b, t, B, W, V, eos, ldtok, s, fused ? nullptr : pad_seen));
         if (t + 1 < max_len) {
             const long rows = (long)N * (t + 1);
             hipLaunchKernelGGL(beam_cache_gather_kernel, dim3((unsigned)((rows + 3) / 4), 2 * L), dim3(256), 0, s, cur, nxt,

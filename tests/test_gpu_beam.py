@@ -146,6 +146,48 @@ def test_cached_beam_one_launch_layers_against_separate_launches(S, W, B):
     close(a[2][same], b[2][same], rtol=1e-4, atol=1e-4, what="scores")
 
 
+@pytest.mark.parametrize("L,S", [(2, 1), (2, 2), (1, 1)])
+def test_cached_beam_follows_pad_hypotheses(L, S):
+    """<PAD> tokens inside hypotheses (vocabulary bias raised): the cached search with the one-launch layers carries
+    those positions along instead of handing the sample to the full-prefix form; hypotheses and scores against the
+    full-prefix form and the oracle."""
+    import ctypes
+    from capdec import _lib, engine
+    from gpu_util import cpu_sd, plain_decoder
+    torch.manual_seed(11 + L)
+    dec = plain_decoder(512, 1500, 4, L).cuda().eval()
+    with torch.no_grad():
+        dec.fc2.bias[R.PAD] += 1.5
+    B, W, ML = 40, 3, 10
+    g = torch.Generator().manual_seed(80 + S)
+    enc = torch.randn(B, S, 512, generator=g)
+    # the cached entry point alone: which samples does it report?
+    lib = _lib.load()
+    ref = engine.TfModelRef(dec)
+    encd = enc.cuda().contiguous()
+    ws = torch.empty(lib.capdec_tf_beam_cached_workspace_bytes(ctypes.byref(ref.c), B, W, S, ML), dtype=torch.uint8, device="cuda")
+    ids = torch.empty((B, ML), dtype=torch.int64, device="cuda")
+    ln = torch.empty((B,), dtype=torch.int32, device="cuda")
+    sc = torch.empty((B, W), dtype=torch.float32, device="cuda")
+    left = torch.empty((1,), dtype=torch.int32, device="cuda")
+    pad = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    _lib.check(lib.capdec_tf_beam_search_cached(ctypes.byref(ref.c), encd.data_ptr(), B, W, S, ML, R.SOS, R.EOS, 0, ML,
+                                                ws.data_ptr(), ws.numel(), ids.data_ptr(), ln.data_ptr(), sc.data_ptr(),
+                                                left.data_ptr(), pad.data_ptr(), torch.cuda.current_stream().cuda_stream), "beam")
+    reported = int(pad.sum())
+    a = dec.beam_ids(encd, R.SOS, R.EOS, W, ML, return_scores=True)
+    b = dec.beam_ids(encd, R.SOS, R.EOS, W, ML, return_scores=True, exact=True)
+    ra, rb = _rows(a[0], a[1]), _rows(b[0], b[1])
+    with_pad = sum(R.PAD in row for row in rb)
+    print(f"L={L} S={S}: {with_pad} best hypotheses hold a <PAD>, {reported} samples reported by the cached search")
+    assert with_pad >= 5 and reported <= B // 4
+    assert sum(x != y for x, y in zip(ra, rb)) <= 2
+    same = [i for i, (x, y) in enumerate(zip(ra, rb)) if x == y]
+    close(a[2][same], b[2][same], rtol=1e-4, atol=1e-4, what="scores")
+    want, _, want_scores = R.beam_search_ids(cpu_sd(dec), enc[:8], 4, W, ML, return_state=True)
+    assert sum(x != y for x, y in zip(ra[:8], want)) <= 1
+
+
 def _peaked_sd(fx, prefix, scale, eos_bias):
     sd = sub_sd(fx, prefix)
     sd["fc2.weight"] = sd["fc2.weight"] * float(scale)
