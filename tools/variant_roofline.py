@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Roofline rows for the kernels that only the secondary workloads of bench.py run (two-memory-row models, the YOLO
-head, long-memory decode, the soft-attention LSTM, beam search, the one-launch decoder layers), from the kernel
+head, long-memory decode, the soft-attention LSTM, beam search), from the kernel
 statistics of one profiled run of the whole bench line:
 
     rocprofv3 --kernel-trace --stats --output-format csv -d OUT -o p -- python3 bench.py --steps 3 --train-steps 3 --no-cpu-baseline
@@ -16,10 +16,7 @@ E, H, V, B = 512, 4, 10000, 1024
 
 # (substring of the kernel name, workload and shape, bound, algorithmic work per launch [FLOP or bytes], note)
 ROWS = [
-    ("decode_layers_team_kernel", "cfg2 decode step, all layers: B=1024, L=2, 1..20 cached keys (mean 10.5)", "mfma",
-     2 * B * (12 * E * E + 4 * 10.5 * E) * 2.0 / 2, "q/k/v/o/fc1/fc2 of both layers + self-attention; 12 E^2 + 4 t E FLOP per row and layer"),
-    ("ln_pair_kernel", "cfg4 / cfg5 decode: 1024 rows, two memory rows", "hbm", (3 + 2 * H) * E * 4.0 * B, "(3 + 2H) E floats per row"),
-    ("attention_memory_kernel", "cfg4-as-worded decode: 1024 rows x 261 raw memory rows", "hbm", 1.0 * B * 261 * E * 4, "the memory once per row"),
+        ("attention_memory_kernel", "cfg4-as-worded decode: 1024 rows x 261 raw memory rows", "hbm", 1.0 * B * 261 * E * 4, "the memory once per row"),
     ("pair_gate_fwd_kernel", "cfg4 training: live rows of 512 x 20 (about 7.5 k), H=4", "hbm", 7488 * 2 * E * 4.0 + 512 * (2 * H + 1) * E * 4.0,
      "x1 read, a2 written per row; G, D per head and c1 once per sample (the 20 rows of a sample share them in cache)"),
     ("pair_gate_bwd_kernel", "cfg4 training: the same rows", "hbm", 7488 * 3 * E * 4.0 + 512 * 4 * H * E * 4.0,
