@@ -287,8 +287,8 @@ def tf_beam_ids(dec, enc, beam_width, max_length, sos, eos, return_scores=False,
     memory per sample.  Returns CPU (ids int64 [B,max_length] padded with -1, lengths int32 [B][, scores [B,W]]):
     the best hypothesis of every sample, without <SOS>, cut at its first <EOS>.
 
-    By default the KV-cached form runs first; samples in which a hypothesis received a <PAD> token (whose query row
-    the reference lets attend uniformly over the current length: no cache can hold that) are then redone with the
+    By default the KV-cached form runs first; the samples it reports (capdec.h: those whose <PAD> hypotheses it could not
+    follow - the reference lets a <PAD> query row attend uniformly over the current length) are then redone with the
     full-prefix form, so the captions are the reference's in every case.  ``exact=True`` uses the full-prefix form for
     every sample.  (The reference leaves its loop when ALL hypotheses of the batch produce <EOS> in one step; a redone
     subset is a batch of its own in that respect: its loop can end earlier than the full batch's did, which changes the

@@ -1,6 +1,7 @@
 // All decoder layers of one KV-cached greedy decode step in ONE launch (transformer.py:83-90 run once per step of
 // the loop at transformer.py:151-171), for the single-memory-row form of the cross-attention block (S == 1: the block
-// is one vector per sample and layer, see capdec_tf_greedy_decode) and at most two layers.
+// is one vector per sample and layer, see capdec_tf_greedy_decode), for two memory rows (S == 2: the logistic closed form,
+// pair_block below) and at most two layers; also the layers of a KV-cached beam-search step over its B*W hypothesis rows.
 //
 // A decode step is a chain of small dependent operations per row: q/k/v projections -> self-attention over the row's
 // own cache -> output projection + residual -> LayerNorm 1, + cross-attention constant, LayerNorm 2 -> fc1 + ReLU ->
@@ -17,9 +18,9 @@
 //     residual;
 //   - between operations the 8 members exchange their 16 x E/8 slices through global memory in a fragment-major
 //     layout ([k/4][row][4 floats]: the 16-byte fragment loads of a consumer are contiguous 1 KiB runs), written with
-//     write-through (sc1) 16-byte stores, published by one agent-scope atomic add per workgroup behind a drain of
-//     every storing wavefront and a workgroup barrier, and read with sc1 loads behind a relaxed poll of that counter
-//     by one lane and a workgroup barrier; teams never wait for one another;
+//     write-through (sc1) 16-byte stores, published by one write-through flag store per workgroup behind a drain of
+//     every storing wavefront and a workgroup barrier, and read with sc1 loads behind a relaxed poll of the team's eight
+//     flags by eight lanes and a workgroup barrier; teams never wait for one another;
 //   - LayerNorm runs on the fragments in registers (row sums over the 8 k-slabs meet in LDS), redundantly in the 8
 //     members, so it costs no hand-off of its own;
 //   - attention: a member takes one head for 8 of the 16 rows (two (row, head) pairs per wavefront, four wavefronts).

@@ -481,8 +481,8 @@ int capdec_event_elapsed_ms(void* begin, void* end, float* ms);
 #define CAPDEC_DECODE_NO_S1_SHORTCUT 1   /* run the general cross-attention kernels even when S == 1 or S == 2 (the
                                             closed forms: one key -> the block is a per-sample constant; two keys ->
                                             a per-sample constant plus one logistic gate per head) */
-#define CAPDEC_DECODE_NO_FUSED_LAYERS 4   /* S == 1, E == 512, H == 4, L <= 8, max_len <= 64: a step's decoder layers run as
-                                            ONE launch (teams of 8 workgroups walk blocks of 32 rows through the whole
+#define CAPDEC_DECODE_NO_FUSED_LAYERS 4   /* S <= 2, E == 512, H == 4, L <= 2, max_len <= 64: a step's decoder layers run as
+                                            ONE launch (teams of 8 workgroups walk blocks of 16 rows through the whole
                                             chain, csrc/decode_fused.hip); this flag keeps the launch-per-operation form.
                                             A workgroup of that launch whose bounded wait for its team runs out sets
                                             out_dirty to 2 for every sample: redo them with capdec_tf_greedy_decode_exact */
@@ -542,9 +542,12 @@ int capdec_tf_beam_search(const capdec_tf_model* m, const float* enc /*[B,S,E]*/
                           int sos, int eos, int t_begin, int t_end, void* workspace, size_t workspace_bytes,
                           int64_t* out_ids, int32_t* out_len, float* out_scores, int32_t* n_unfinished, void* stream);
 /* KV-cached form of capdec_tf_beam_search: one new position per hypothesis and step, the key/value caches re-gathered
- * after every selection.  pad_seen [B] (device) is set for samples in which some hypothesis received a <PAD> token:
- * the reference lets a <PAD> query row attend uniformly over the CURRENT length (transformer.py:117-123), which no
- * cache reproduces, so the caller redoes exactly those samples with capdec_tf_beam_search. */
+ * after every selection.  The reference lets a <PAD> query row attend uniformly over the CURRENT length
+ * (transformer.py:117-123), which a plain cache does not reproduce.  pad_seen [B] (device) is set for the samples the
+ * caller must redo with capdec_tf_beam_search: with the one-launch decoder layers (the shapes listed at
+ * CAPDEC_DECODE_NO_FUSED_LAYERS, over B*W rows) the <PAD> positions of a hypothesis follow along and only a block of 16
+ * hypotheses with more than 16 of them, or a wait that ran out, reports its samples; otherwise every sample in which
+ * some hypothesis received a <PAD> token. */
 size_t capdec_tf_beam_cached_workspace_bytes(const capdec_tf_model* m, int B, int W, int S, int max_len);
 int capdec_tf_beam_search_cached(const capdec_tf_model* m, const float* enc, int B, int W, int S, int max_len, int sos,
                                  int eos, int t_begin, int t_end, void* workspace, size_t workspace_bytes,
