@@ -74,6 +74,12 @@ int main() {
     EXPECT(capdec_attention(nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 1, 1, 1, 1, 64, 0, 0, nullptr, 0, nullptr,
                             nullptr), CAPDEC_EINVAL);
     EXPECT(capdec_dropout(a, 16, 1.0f, 1, nullptr, a, nullptr), CAPDEC_EINVAL);                   // p must be < 1
+    EXPECT(capdec_layernorm_bwd_workspace_floats(0, 64), 0);
+    EXPECT(capdec_layernorm_bwd_workspace_floats(1024, 512) >= (size_t)3 * 512, 1);
+    EXPECT(capdec_layernorm_bwd_staged(a, a, a, a, a, 4, 64, 0.f, 1, nullptr, a, a, a, a, a, nullptr, a, 1, nullptr),
+           CAPDEC_ENOMEM);                                                                        // workspace too small
+    EXPECT(capdec_layernorm_bwd_staged(nullptr, a, a, a, a, 4, 64, 0.f, 1, nullptr, a, a, a, a, a, nullptr, nullptr, 0,
+                                       nullptr), CAPDEC_EINVAL);
     EXPECT(capdec_dropout(nullptr, 16, 0.1f, 1, nullptr, a, nullptr), CAPDEC_EINVAL);
     EXPECT(capdec_add_layernorm_train_rows(a, 0, nullptr, a, a, a, 1e-5f, 4, 64, 0.1f, 1, nullptr, a, a, a, a, nullptr,
                                            nullptr), CAPDEC_EINVAL);                              // x_div < 1

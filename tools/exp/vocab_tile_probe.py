@@ -1,33 +1,56 @@
 #!/usr/bin/env python3
-"""Times the vocabulary projection + arg-max launch (1024 x 10000 x 512) of whatever libcapdec.so is in place and checks
-the ids against a float64 product (ties aside)."""
-import json
+"""The two vocabulary contractions of the cfg3 training step that run on gemm_kernel's automatic tile rule - logits
+(M x V x E, forward layout) and their input gradient (M x E x V, (n,t) layout) - per forced tile configuration."""
+import ctypes
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "image-captioning_amd"))
 import torch
-from capdec import ops
+from capdec import _lib
 
-torch.manual_seed(0)
-M, V, E = 1024, 10000, 512
-x = torch.randn(M, E, device="cuda")
-W = torch.randn(V, E, device="cuda") * 0.05
-b = torch.randn(V, device="cuda") * 0.1
-ids = ops.vocab_argmax(x, W, b)
-ids = ids[0] if isinstance(ids, tuple) else ids
-ref = (x.double() @ W.double().t() + b.double()).argmax(1)
-bad = int((ids.long() != ref).sum())
-for _ in range(20):
-    ops.vocab_argmax(x, W, b)
-torch.cuda.synchronize()
-n = 300
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(n):
-    ops.vocab_argmax(x, W, b)
-e1.record()
-torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / n * 1e3
-print(json.dumps({"us_per_call_incl_finalize": us, "mismatch_vs_f64": bad, "tflops": 2.0 * M * V * E / us / 1e6}))
+lib = _lib.tuning_build().__enter__()
+s = torch.cuda.current_stream().cuda_stream
+E, V = 512, 10000
+
+
+def run(M, I, J, K, cfg, tq, reps=10):
+    P = torch.randn(I, K, device="cuda")
+    Q = torch.randn(K, J, device="cuda") if tq else torch.randn(J, K, device="cuda")
+    C = torch.empty(I, J, device="cuda")
+    g = (_lib.GemmGroup * 1)()
+    g[0].P, g[0].Q, g[0].C = P.data_ptr(), Q.data_ptr(), C.data_ptr()
+    g[0].ldp, g[0].ldq, g[0].ldci, g[0].ldcj, g[0].I, g[0].J = K, (J if tq else K), J, 1, I, J
+    ex = _lib.GemmExtra()
+    lib.capdec_gemm_force_config(cfg)
+    flags = _lib.GEMM_TQ if tq else 0
+
+    def go():
+        rc = lib.capdec_gemm_ex(g, 1, K, flags, ctypes.byref(ex), s)
+        assert rc == 0, rc
+
+    for _ in range(3):
+        go()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        go()
+    b.record()
+    torch.cuda.synchronize()
+    lib.capdec_gemm_force_config(0)
+    us = a.elapsed_time(b) * 1e3 / reps
+    return us, 2.0 * I * J * K / us / 1e6
+
+
+for M in (7488, 10240):
+    for name, (I, J, K, tq) in (("logits", (M, V, E, False)), ("input gradient", (M, E, V, True))):
+        row = f"M={M:6d} {name:15s}: "
+        for c in (0, 116, 11, 2116, 2132, 216, 22):
+            try:
+                us, tf = run(M, I, J, K, c, tq)
+                row += f"cfg {c}: {us:6.1f} us {tf / 157.3 * 100:4.1f} %   "
+            except AssertionError as e:
+                row += f"cfg {c}: rc {e}   "
+        print(row, flush=True)
