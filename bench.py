@@ -766,8 +766,8 @@ def main():
                                    f"memory rows S={S}" + (" (reference-faithful pooled feature)" if S == 1 else
                                                            " (feature-grid variant)"),
                        "global_batch": world * B, "max_length": LEN, "rows_redecoded_exactly_per_step": dirty_rows / args.steps,
-                       "step_structure": "3 launches: token pick + embedding, all decoder layers (teams of 8 workgroups per "
-                                         "32 rows), vocabulary projection + arg-max" if S == 1 else "one launch per operation"},
+                       "step_structure": "2 launches: all decoder layers incl. the previous step's token pick (teams of 8 "
+                                         "workgroups per 16 rows), vocabulary projection + arg-max" if S <= 2 else "one launch per operation"},
             "roofline": {"bound": "mfma", "kernel": "vocab_reduce_kernel (fc2 projection + fused arg-max)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "avg_launch_ms": avg_ms,
