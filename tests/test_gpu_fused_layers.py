@@ -135,3 +135,30 @@ def test_one_launch_layers_at_the_benchmark_batch():
     same = sum(a == b for a, b in zip(fused, plain))
     assert same >= B - 4, same
     check_greedy(fused[:40], cpu_sd(dec), enc[:40], H, ML)
+
+
+def test_one_launch_layers_bit_identical_under_uneven_load():
+    """The hand-offs between the workgroups of a team must not depend on what else the chip is doing: the same decode,
+    alone and beside a stream of large contractions that come and go (other CUs busy at times, two teams per CU at
+    1024 rows, caches warm from the previous run), gives the same rows bit for bit and the same captions."""
+    from capdec.engine import tf_greedy_ids
+    V, B, ML = 3000, 1024, 12
+    dec = _decoder(2, V, 9, pad_bias=0.9)
+    g = torch.Generator().manual_seed(15)
+    enc = torch.randn(B, 1, E, generator=g).cuda()
+    quiet = []
+    ids0, len0, _ = tf_greedy_ids(dec, enc, ML, R.SOS, R.EOS, keep_workspace=quiet)
+    torch.cuda.synchronize()
+    x0 = quiet[0][:B * E * 4].clone()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    b = torch.randn(4096, 4096, device="cuda")
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(3 + 2 * rep):
+                a @ b                                   # bursts of different lengths beside the decode
+        ws = []
+        ids, lens, _ = tf_greedy_ids(dec, enc, ML, R.SOS, R.EOS, keep_workspace=ws)
+        torch.cuda.synchronize()
+        assert torch.equal(ids, ids0) and torch.equal(lens, len0), rep
+        assert torch.equal(ws[0][:B * E * 4], x0), rep
