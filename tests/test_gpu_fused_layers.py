@@ -162,3 +162,21 @@ def test_one_launch_layers_bit_identical_under_uneven_load():
         torch.cuda.synchronize()
         assert torch.equal(ids, ids0) and torch.equal(lens, len0), rep
         assert torch.equal(ws[0][:B * E * 4], x0), rep
+
+
+def test_one_launch_layers_at_the_longest_supported_captions():
+    """max_length 64 (the limit of the one-launch form): every pass of the attention stage over 16 keys and every block
+    of values is exercised; captions against the launch-per-operation form and, for a few rows, the oracle."""
+    V, B, ML = 800, 24, 64
+    torch.manual_seed(21)
+    dec = plain_decoder(E, V, H, 2, max_len=ML).cuda().eval()
+    with torch.no_grad():
+        dec.fc2.bias[R.PAD] += 0.6
+        dec.fc2.bias[R.EOS] -= 5.0
+    g = torch.Generator().manual_seed(64)
+    enc = torch.randn(B, 1, E, generator=g)
+    fused, _ = _ids(dec, enc, ML)
+    plain, _ = _ids(dec, enc, ML, fused_layers=False)
+    assert max(len(r) for r in fused) == ML
+    ties = check_greedy(fused[:6], cpu_sd(dec), enc[:6], H, ML)
+    assert sum(a == b for a, b in zip(fused, plain)) >= B - max(2, ties)
