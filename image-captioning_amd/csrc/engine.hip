@@ -1016,10 +1016,23 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
     if (s1) {
         // softmax over one key is exactly 1, so the block's output is W_o(W_v enc + b_v) + b_o for every
         // query: one vector per sample and layer, computed once
-        for (int l = 0; l < L; ++l) {
-            const capdec_attn_w& a = m->layers[l].cross_attn;
-            CAPDEC_TRY(linear(enc, E, B, a.wv, a.bv, E, E, w.ao, E, nullptr, 0, 0, s));
-            CAPDEC_TRY(linear(w.ao, E, B, a.wo, a.bo, E, E, w.cc + l * BE, E, nullptr, 0, 0, s));
+        // (up to four layers per grouped launch; w.ao, w.hb, w.q, w.y are free until the first step)
+        float* tmp[4] = {w.ao, w.hb, w.q, w.y};
+        for (int l0 = 0; l0 < L; l0 += 4) {
+            const int n = L - l0 < 4 ? L - l0 : 4;
+            capdec_gemm_group g[4];
+            for (int k = 0; k < n; ++k) {
+                const capdec_attn_w& a = m->layers[l0 + k].cross_attn;
+                g[k] = linear_group(enc, E, B, a.wv, a.bv, E, tmp[k], E);
+                g[k].ldq = E;
+            }
+            CAPDEC_TRY(capdec_launch_gemm(g, n, E, 0, s));
+            for (int k = 0; k < n; ++k) {
+                const capdec_attn_w& a = m->layers[l0 + k].cross_attn;
+                g[k] = linear_group(tmp[k], E, B, a.wo, a.bo, E, w.cc + (size_t)(l0 + k) * BE, E);
+                g[k].ldq = E;
+            }
+            CAPDEC_TRY(capdec_launch_gemm(g, n, E, 0, s));
         }
     } else if (fold) {
         CAPDEC_TRY(fold_memory_weights(m, w.fw1, w.fb1, w.fw2, w.fb2, s));
