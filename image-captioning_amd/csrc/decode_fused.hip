@@ -136,20 +136,22 @@ __device__ __forceinline__ void mma_entry(const float* slot, int wave, int lane,
     using C = FT<E>;
     const int c = lane & 15, g = lane >> 4;
     const float* img = slot + wave * C::WSLAB;
+    // (the two column tiles in turn inside the m loop: consecutive MFMAs never depend on one another)
+    f32x4 b[2][2];
 #pragma unroll
-    for (int kq = 0; kq < 2; ++kq) {
+    for (int kq = 0; kq < 2; ++kq)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int row = ct * 16 + c;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(img + row * 32 + ((((kq * 4 + g) ^ ((row >> 1) & 7))) << 2));
-#ifdef FT_EXPERIMENT_NO_MFMA    // timing experiment only (tools/exp)
-            acc2[ct] += b * a2[kq][0];
-#else
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kq][m], b[m], acc2[ct], 0, 0, 0);
-#endif
+            b[kq][ct] = *reinterpret_cast<const f32x4*>(img + row * 32 + ((((kq * 4 + g) ^ ((row >> 1) & 7))) << 2));
         }
-    }
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kq][m], b[kq][ct][m], acc2[ct], 0, 0, 0);
 }
 
 // NPROJ projections of the 16-row tile streamed through the ring.  The stream of entries W[0] e0..e3, W[1] e0.., ...
