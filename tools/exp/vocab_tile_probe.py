@@ -46,11 +46,10 @@ def run(M, I, J, K, cfg, tq, reps=10):
 
 for M in (7488, 10240):
     for name, (I, J, K, tq) in (("logits", (M, V, E, False)), ("input gradient", (M, E, V, True))):
-        row = f"M={M:6d} {name:15s}: "
-        for c in (0, 116, 11, 2116, 2132, 216, 22):
-            try:
-                us, tf = run(M, I, J, K, c, tq)
-                row += f"cfg {c}: {us:6.1f} us {tf / 157.3 * 100:4.1f} %   "
-            except AssertionError as e:
-                row += f"cfg {c}: rc {e}   "
-        print(row, flush=True)
+        cfgs = (116, 11, 2116, 2132, 216, 0)
+        best = {c: 1e9 for c in cfgs}
+        for rnd in range(3):                       # every configuration in every round: the first one pays no warm-up alone
+            for c in cfgs:
+                us, _ = run(M, I, J, K, c, tq)
+                best[c] = min(best[c], us)
+        print(f"M={M:6d} {name:15s}: " + "   ".join(f"cfg {c}: {best[c]:6.1f} us {2.0 * I * J * K / best[c] / 1e6 / 157.3 * 100:4.1f} %" for c in cfgs), flush=True)
