@@ -545,6 +545,32 @@ def variants_bench(device, steps=6, warmup=2):
     _, dt_b = timed(lambda: model.caption_ids_beam(feats_h, beam_width=3, max_length=LEN), 3)
     out["beam_w3"] = {"workload": f"cfg2 CNN-Attn beam search, width 3, S=1, B={B}, len {LEN} (KV caches re-gathered by parent)",
                       "value": B / dt_b, "unit": "captions/s", "ms_per_step": dt_b * 1e3}
+    # ---- the headline workload with step k+1 enqueued before step k's ids are waited for (one stream, one batch at a
+    #      time on the GPU): what the host does between two batches no longer idles the chip ----
+    ref_h = engine.TfModelRef(model)
+
+    def enqueue():
+        with torch.no_grad():
+            enc = model.encode_features(feats_h).view(B, 1, E)
+            return engine.tf_greedy_ids_async(ref_h, enc, LEN, 1, 2)
+
+    for n in (warmup, steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        prev = None
+        for _ in range(n):
+            cur_p = enqueue()
+            if prev is not None:
+                prev.result()
+            prev = cur_p
+        if prev is not None:
+            prev.result()
+        torch.cuda.synchronize()
+        dt_p = (time.perf_counter() - t0) / max(n, 1)
+    out["decode_enqueued_one_step_ahead"] = {
+        "workload": f"cfg2 CNN-Attn greedy decode, S=1, B={B}, len {LEN}: the next batch is enqueued before the ids of the "
+                    "current one are waited for (tf_greedy_ids_async)",
+        "value": B / dt_p, "unit": "captions/s", "ms_per_step": dt_p * 1e3}
     # the same search at the reference's evaluation batch size (eval.py:91-102 draws batches of 64): here the decoder
     # layers of a step run as one launch inside the cached search
     _, dt_b64 = timed(lambda: model.caption_ids_beam(feats_h[:64], beam_width=3, max_length=LEN), 5)

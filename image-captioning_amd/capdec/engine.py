@@ -92,12 +92,13 @@ class VocabProbe:
 
 
 def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=False, resolve_dirty=True, probe=None,
-                  to_cpu=True, extra_cap=0, fold_memory=False, fused_layers=True, keep_workspace=None):
+                  to_cpu=True, extra_cap=0, fold_memory=False, fused_layers=True, keep_workspace=None, keep_pack=None):
     """Greedy decode on the GPU.  enc [B,S,E] fp32.  Returns (ids int64 [B,max_length] padded with -1, lengths
     int32 [B], number of rows that went through the exact path).  ids/lengths are CPU tensors unless
     ``to_cpu=False`` (then they stay on the device, e.g. for a cross-rank gather).  ``fused_layers=False`` keeps the
     launch-per-operation form of a step where the library would run all decoder layers as one launch (capdec.h,
-    CAPDEC_DECODE_NO_FUSED_LAYERS).  ``keep_workspace``: a list that receives the workspace tensor (tests)."""
+    CAPDEC_DECODE_NO_FUSED_LAYERS).  ``keep_workspace``: a list that receives the workspace tensor (tests);
+    ``keep_pack``: a list that receives the device allocation holding ids, lengths and flags back to back."""
     lib = _lib.load()
     if not enc.is_cuda or enc.dtype != torch.float32:
         raise RuntimeError("capdec: enc must be an fp32 tensor on the GPU (HIP); there is no CPU path")
@@ -113,6 +114,8 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
     out_ids = pack[:n_ids].view(torch.int64).view(B, max_length)
     out_len = pack[n_ids:n_ids + B]
     dirty = pack[n_ids + B:]
+    if keep_pack is not None:
+        keep_pack.append(pack)
 
     def to_host():
         host = torch.empty(pack.shape, dtype=torch.int32, pin_memory=True)
@@ -173,6 +176,47 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
                 host = to_host()
         return host[0], host[1], n_dirty
     return out_ids, out_len, n_dirty
+
+
+class PendingCaptions:
+    """A greedy decode that has been enqueued but not waited for (``tf_greedy_ids_async``): the ids, lengths and flags
+    are on their way to pinned host memory behind an event on the decode's stream.  ``result()`` waits for that event
+    only, re-decodes flagged samples on the exact path if there are any, and returns what ``tf_greedy_ids`` returns.
+    A serving loop enqueues batch k+1 before it asks for batch k, so the host's work between two batches (feature
+    head, argument set-up, the wait itself) no longer leaves the GPU idle."""
+
+    def __init__(self, dec, enc, max_length, sos, eos, pack, host, event):
+        self._args = (dec, enc, max_length, sos, eos)
+        self._pack, self._host, self._event = pack, host, event
+
+    def result(self):
+        dec, enc, max_length, sos, eos = self._args
+        B = enc.shape[0]
+        n_ids = 2 * B * max_length
+        self._event.synchronize()
+        host = self._host
+        ids = host[:n_ids].view(torch.int64).view(B, max_length)
+        lens, dirty = host[n_ids:n_ids + B], host[n_ids + B:]
+        if not bool(dirty.any()):
+            return ids, lens, 0
+        # rare: samples the cached decode could not follow (capdec.h, out_dirty): the synchronous wrapper redoes them
+        return tf_greedy_ids(dec, enc, max_length, sos, eos)
+
+
+def tf_greedy_ids_async(dec, enc, max_length, sos, eos):
+    """``tf_greedy_ids`` without the wait: enqueues the decode and the copy of its results to pinned host memory on the
+    current stream and returns a ``PendingCaptions``."""
+    dev = enc.device
+    B = enc.shape[0]
+    kept = []
+    tf_greedy_ids(dec, enc, max_length, sos, eos, resolve_dirty=False, to_cpu=False, keep_pack=kept)
+    pack = kept[0]                                  # ids, lengths and flags in one allocation: one copy brings all three
+    host = torch.empty(pack.shape, dtype=torch.int32, pin_memory=True)
+    with torch.cuda.device(dev):
+        host.copy_(pack, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(dev))
+    return PendingCaptions(dec, enc, max_length, sos, eos, pack, host, event)
 
 
 def _exact(lib, ref, enc, max_length, sos, eos, out_ids, out_len):

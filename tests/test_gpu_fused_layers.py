@@ -180,3 +180,22 @@ def test_one_launch_layers_at_the_longest_supported_captions():
     assert max(len(r) for r in fused) == ML
     ties = check_greedy(fused[:6], cpu_sd(dec), enc[:6], H, ML)
     assert sum(a == b for a, b in zip(fused, plain)) >= B - max(2, ties)
+
+
+def test_greedy_decode_enqueued_ahead_equals_the_synchronous_call():
+    """tf_greedy_ids_async: three batches enqueued before the first result is asked for, one of them with samples the
+    cached decode hands to the exact path; ids and lengths equal the synchronous wrapper's."""
+    from capdec.engine import TfModelRef, tf_greedy_ids, tf_greedy_ids_async
+    V, ML = 500, 10
+    dec = _decoder(2, V, 3, pad_bias=1.5)
+    ref = TfModelRef(dec)
+    g = torch.Generator().manual_seed(8)
+    encs = [torch.randn(b, 1, E, generator=g).cuda() for b in (64, 17, 40)]
+    pending = [tf_greedy_ids_async(ref, e, ML, R.SOS, R.EOS) for e in encs]
+    redone = 0
+    for e, p in zip(encs, pending):
+        ids, lens, nd = p.result()
+        want = tf_greedy_ids(ref, e, ML, R.SOS, R.EOS)
+        assert torch.equal(ids, want[0]) and torch.equal(lens, want[1]) and nd == want[2]
+        redone += nd
+    assert redone > 0
