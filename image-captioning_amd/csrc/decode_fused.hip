@@ -522,13 +522,6 @@ void decode_layers_team_kernel(capdec_fused_args A) {
     (void)jb; (void)tb_; (void)frag_off; (void)ja; (void)ta
     const int cache_bytes = A.cache_bytes;
 
-#ifdef FT_PRIO         // timing experiment (tools/exp): the first half of the teams at a higher wavefront priority
-    if (team < (A.teams + 1) / 2) __builtin_amdgcn_s_setprio(FT_PRIO);
-#endif
-#ifdef FT_STAGGER      // timing experiment (tools/exp): the second half of the teams starts FT_STAGGER microseconds late
-    if (team >= (A.teams + 1) / 2)
-        for (int i = 0; i < FT_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
-#endif
     FT_MARK();                                   // 0: set-up done
     for (int l = 0; l < A.L; ++l) {
         const capdec_fused_layer& ly = A.ly[l];
