@@ -58,15 +58,17 @@ def _workspace(nbytes, device):
 
 
 class VocabProbe:
-    """HIP events around the vocabulary-projection kernel of each decode step (benchmark plumbing)."""
+    """HIP events around the vocabulary-projection kernel of decode steps ``first, first + every, ...`` below ``n``
+    (benchmark plumbing; every record takes about 3 us of stream time, which is why a caller may sample)."""
 
-    def __init__(self, n):
+    def __init__(self, n, every=1, first=0):
         lib = _lib.load()
         self.n = n
-        self.begin = (ctypes.c_void_p * n)()
+        self.steps = [i for i in range(n) if i >= first and (i - first) % every == 0]
+        self.begin = (ctypes.c_void_p * n)()          # entries left null: steps that are not timed
         self.end = (ctypes.c_void_p * n)()
         for arr in (self.begin, self.end):
-            for i in range(n):
+            for i in self.steps:
                 ev = ctypes.c_void_p()
                 _lib.check(lib.capdec_event_create(ctypes.byref(ev)), "capdec_event_create")
                 arr[i] = ev
@@ -77,7 +79,7 @@ class VocabProbe:
         """Per-step kernel durations; call after the stream has been synchronised."""
         lib = _lib.load()
         out = []
-        for i in range(self.n):
+        for i in self.steps:
             ms = ctypes.c_float()
             _lib.check(lib.capdec_event_elapsed_ms(self.begin[i], self.end[i], ctypes.byref(ms)), "capdec_event_elapsed_ms")
             out.append(ms.value)
@@ -86,9 +88,9 @@ class VocabProbe:
     def close(self):
         lib = _lib.load()
         for arr in (self.begin, self.end):
-            for i in range(self.n):
+            for i in self.steps:
                 lib.capdec_event_destroy(arr[i])
-        self.n = 0
+        self.n, self.steps = 0, []
 
 
 def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=False, resolve_dirty=True, probe=None,

@@ -1136,7 +1136,7 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
                                                     rows, s));
         }
         // only the B new rows predict a token
-        const bool probed = probe && t < probe->n;
+        const bool probed = probe && t < probe->n && probe->begin[t] && probe->end[t];
         if (probed) CAPDEC_TRY((int)hipEventRecord((hipEvent_t)probe->begin[t], s));
         CAPDEC_TRY(capdec_launch_vocab_argmax_rows(w.x, E, m->fc2_w, m->fc2_b, B, V, E, w.pval, w.pidx, rows, s));
         if (probed) CAPDEC_TRY((int)hipEventRecord((hipEvent_t)probe->end[t], s));

@@ -461,7 +461,8 @@ size_t capdec_tf_decode_workspace_bytes(const capdec_tf_model* m, int B, int S, 
  * With S == 1 the softmax over the single memory row is exactly 1,
  * so the cross-attention block reduces to one vector per sample and layer that is computed once. */
 /* Optional timing probe: HIP events recorded on `stream` right before / after the vocabulary-projection
- * kernel of decode step t, for t < n.  Events are created with capdec_event_create; read them with
+ * kernel of decode step t, for every t < n whose two array entries are both non-null (a record costs about 3 us of
+ * stream time, so a caller may time every k-th step only).  Events are created with capdec_event_create; read them with
  * capdec_event_elapsed_ms after the stream has been synchronised.  Measurement plumbing only: it has no
  * counterpart in the reference. */
 typedef struct capdec_probe {

@@ -40,3 +40,13 @@ for it in range(N):
     tt += time.perf_counter() - t0
 print(f"feature head (host) {acc[0] / N * 1e6:.0f} us, decode call returns after {acc[1] / N * 1e6:.0f} us, "
       f"GPU done {acc[2] / N * 1e6:.0f} us later; synchronous step {tt / N * 1e3:.3f} ms")
+# the same synchronous step with the benchmark's HIP events around each vocabulary kernel
+probe = engine.VocabProbe(LEN)
+tp = 0.0
+for it in range(N):
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        enc = model.encode_features(feats).view(B, 1, E)
+    engine.tf_greedy_ids(ref, enc, LEN, 1, 2, to_cpu=True, probe=probe)
+    tp += time.perf_counter() - t0
+print(f"synchronous step with {2 * LEN} event records in the stream {tp / N * 1e3:.3f} ms")
