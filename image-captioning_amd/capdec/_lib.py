@@ -123,6 +123,9 @@ _SIGNATURES = {
                                             _P, c_size_t, _P]),
     "capdec_group_sum_segments": (c_int, [_P, c_int, _P, c_int, _P, _P]),
     "capdec_embed_bwd_rows": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "capdec_embed_train_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P]),
+    "capdec_embed_train_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_uint64, _P, _P, _P, _P]),
+    "capdec_compact_prefix_strided": (c_int, [_P, _P, c_int64, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "capdec_compact_prefix": (c_int, [_P, _P, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "capdec_attention_ragged": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, _P,
                                         _P, _P, _P]),

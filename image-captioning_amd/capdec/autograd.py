@@ -302,23 +302,25 @@ def tf_forward(dec, enc, ids, p, seed, single_row_shortcut=True, ragged=None, se
     t.shortcut = S == 1 and single_row_shortcut
     t.pair = S == 2 and pair_cross is not False and not absorb_cross and E % (4 * H) == 0 and E <= 1024
     t.absorbed = not (t.shortcut or t.pair) and absorb_cross is not False and (absorb_cross or cross_absorbed(S, T, E, H))
-    t.ids = ids.contiguous()
-    t.ids32 = t.ids.to(torch.int32)
     t.enc = enc.reshape(B * S, E)
     pe = dec.positional_encoding.pe[0]
     if T > pe.shape[0]:
         raise RuntimeError(f"capdec: sequence length {T} exceeds the positional-encoding buffer ({pe.shape[0]})")
-    x = ops.embed_pe(t.ids, dec.decoder_embedding.weight, pe)
     t.ragged = ragged
     rows = None
+    # embedding + position + dropout (and, on a ragged batch, the move of the live rows to their slots) as one launch;
+    # the ids may be a strided view (captions[:, :-1])
     if ragged is not None:
         if not ragged_supported(dec, S, T, B) or (ragged.B, ragged.T) != (B, T):
             raise RuntimeError("capdec tf_forward: this configuration cannot run on a ragged batch (see ragged_supported)")
         rows = ragged.rows
-        x = x.index_select(0, ragged.order)
-        t.ids_c = t.ids.view(-1).index_select(0, ragged.order)
-    if p > 0:
-        x = ops.dropout(x, p, seed, seed_dev=seed_dev)
+        t.ids = t.ids32 = None                       # (the dense ids are not needed again)
+        x, t.ids_c = ops.embed_train(ids, dec.decoder_embedding.weight, pe, p, seed, seed_dev=seed_dev, order=ragged.order,
+                                     want_ids=True)
+    else:
+        t.ids = ids.contiguous()
+        t.ids32 = t.ids.to(torch.int32)
+        x = ops.embed_train(t.ids, dec.decoder_embedding.weight, pe, p, seed, seed_dev=seed_dev)
     t.layers = []
     pre_cc = None
     if t.shortcut and _side() is not None:
@@ -526,10 +528,10 @@ def tf_backward(dec, t, dx, grads, need_denc=True, on_layer_done=None):
         dx = d_x
         if on_layer_done is not None:
             on_layer_done(l)          # every gradient of layer l is now enqueued
-    if p > 0:
-        dx = ops.dropout(dx, p, t.seed, seed_dev=t.seed_dev)
+    # (the dropout of the embedding rows is undone by the scatter kernel itself: same mask, no launch in between)
     ops.embed_bwd(t.ids.view(-1) if rg is None else t.ids_c, dx,
-                  _new(grads, "decoder_embedding.weight", dec.decoder_embedding.weight), rows_dev=rows)
+                  _new(grads, "decoder_embedding.weight", dec.decoder_embedding.weight), rows_dev=rows, p=p, seed=t.seed,
+                  seed_dev=t.seed_dev)
     if side_used and need_denc:
         torch.cuda.current_stream().wait_stream(_side())        # denc was accumulated on the side stream
     return denc.view(B, S, E) if need_denc else None

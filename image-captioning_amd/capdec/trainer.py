@@ -24,6 +24,11 @@ from . import ops
 from .autograd import Tape
 
 
+def captions_strided_ok(ids, tgt):
+    """Whether the two views can be read in place by the compaction and embedding kernels."""
+    return ids.dim() == 2 and ids.stride(1) == 1 and tgt.stride(1) == 1 and ids.stride(0) == tgt.stride(0)
+
+
 def _head_spec(model):
     """(parts, names, dropout_first) of the model's feature head, mirroring models/modules/heads.py."""
     if hasattr(model, "fc_yolo") and hasattr(model, "fc_cnn"):
@@ -206,13 +211,14 @@ class CaptionTrainer:
         backward.  reduce_inside: issue the per-segment all-reduces while the backward pass is enqueued."""
         self.state.advance(self.betas[0], self.betas[1])
         self.flat_g.zero_()
-        ids = captions[:, :-1].contiguous()
-        tgt = captions[:, 1:].contiguous()
+        # inputs and targets as two views of the caption matrix (train.py:253-256); the Transformer path on live rows
+        # reads them in place, every other path gets packed copies
+        ids, tgt = captions[:, :-1], captions[:, 1:]
         self._reduce_on = reduce_inside
         AG.use_side_stream(self.side_stream)
         try:
             if self.rnn is not None:
-                loss = self._rnn_step(feats, ids, tgt)
+                loss = self._rnn_step(feats, ids.contiguous(), tgt.contiguous())
             else:
                 loss = self._tf_step(feats, ids, tgt)
             AG.join_side_stream()
@@ -332,8 +338,10 @@ class CaptionTrainer:
         B = feats.shape[0]
         enc = y.view(B, len(parts), -1)
         rg = None
-        if self.skip_dead_rows and AG.ragged_supported(model, enc.shape[1], ids.shape[1], B):
+        if self.skip_dead_rows and AG.ragged_supported(model, enc.shape[1], ids.shape[1], B) and captions_strided_ok(ids, tgt):
             rg = ops.RaggedRows(ids, tgt, self.pad_idx)
+        else:
+            ids, tgt = ids.contiguous(), tgt.contiguous()
         x, tape = AG.tf_forward(model, enc, ids, p, self._SEED_DECODER, ragged=rg, seed_dev=sdev)
         if rg is not None:
             loss, saved = AG.vocab_loss(model, x, rg.targets_c, self.pad_idx, rows=rg.rows)

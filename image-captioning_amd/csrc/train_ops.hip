@@ -582,6 +582,36 @@ __global__ void axpy_rows_kernel(const float* __restrict__ x, int x_div, float s
     }
 }
 
+// ---- embedding forward of a training step: x[s,:] = dropout(emb[id,:] + pe[i,:]) for slot s, whose dense row
+// r = order[s] (or s) is position i = r % T of sample r / T and whose id sits at ids[(r / T)*ldid + i]; the mask is the
+// one dropout4_kernel draws for element s*E + c of the output.  One wavefront per slot.
+__global__ __launch_bounds__(256) void embed_train_fwd_kernel(const int64_t* __restrict__ ids, int64_t ldid,
+                                                              const int64_t* __restrict__ order,
+                                                              const float* __restrict__ emb, const float* __restrict__ pe,
+                                                              int M, int T, int E, int V, float p, uint64_t seed,
+                                                              const uint64_t* __restrict__ seed_dev, float* __restrict__ x,
+                                                              int64_t* __restrict__ ids_out) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (s >= M) return;
+    if (seed_dev) seed += seed_dev[0];
+    const int64_t r = order ? order[s] : s;
+    const int b = (int)(r / T), i = (int)(r - (int64_t)b * T);
+    const int64_t raw = ids[(int64_t)b * ldid + i];
+    if (ids_out && lane == 0) ids_out[s] = raw;
+    const int64_t id = raw < 0 ? 0 : (raw >= V ? V - 1 : raw);
+    const f32x4* src = reinterpret_cast<const f32x4*>(emb + id * (int64_t)E);
+    const f32x4* pp = pe ? reinterpret_cast<const f32x4*>(pe + (int64_t)i * E) : nullptr;
+    f32x4* dst = reinterpret_cast<f32x4*>(x + (int64_t)s * E);
+    const float inv_keep = 1.0f / (1.0f - p);
+    for (int c = lane; c < E / 4; c += 64) {
+        f32x4 v = src[c];
+        if (pp) v += pp[c];
+        if (p > 0.f) v *= drop_scale4(seed, (uint64_t)s * E + 4 * c, p, inv_keep);
+        dst[c] = v;
+    }
+}
+
 // ---- embedding backward: demb[ids[r], :] += dx[r, :] ----------------------------------------------
 // Same-address float atomics serialise, and a few ids are very frequent: the reference's vocabulary reserves
 // ids 0..3 for <PAD>/<SOS>/<EOS>/<UNK> (get_loader.py:28-29), <SOS> opens every caption and <PAD> fills the
@@ -594,10 +624,15 @@ constexpr int EB_HOT = 4;
 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
                                                         int rows, int E, int V, float* __restrict__ demb,
-                                                        const int32_t* __restrict__ rows_dev, int EB_ROWS) {
+                                                        const int32_t* __restrict__ rows_dev, int EB_ROWS, float p,
+                                                        uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    // p > 0: dx is the gradient behind a dropout of the embedding rows (embed_train_fwd_kernel): element (row, c) is
+    // scaled by the mask of element row*E + c first, exactly as a dropout launch in front of this one would
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [EB_HOT][E]
     __shared__ int used[EB_HOT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (seed_dev) seed += seed_dev[0];
+    const float inv_keep = 1.0f / (1.0f - p);
     if (rows_dev) rows = min(rows, rows_dev[0]);
     if ((int)blockIdx.x * EB_ROWS >= rows) return;
     for (int c = threadIdx.x; c < EB_HOT * E; c += 256) lds[c] = 0.f;
@@ -609,12 +644,15 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
         long id = ids[row];
         id = id < 0 ? 0 : (id >= V ? V - 1 : id);
         const float* src = dx + (int64_t)row * E;
+        const uint64_t e0 = (uint64_t)row * E;
         if (id < EB_HOT) {
             if (lane == 0) used[id] = 1;
-            for (int c = lane; c < E; c += 64) atomicAdd(&lds[id * E + c], src[c]);
+            for (int c = lane; c < E; c += 64)
+                atomicAdd(&lds[id * E + c], p > 0.f ? src[c] * drop_scale(seed, e0 + c, p, inv_keep) : src[c]);
         } else {
             float* dst = demb + id * (int64_t)E;
-            for (int c = lane; c < E; c += 64) atomicAdd(&dst[c], src[c]);
+            for (int c = lane; c < E; c += 64)
+                atomicAdd(&dst[c], p > 0.f ? src[c] * drop_scale(seed, e0 + c, p, inv_keep) : src[c]);
         }
     }
     __syncthreads();
@@ -1429,7 +1467,7 @@ __global__ __launch_bounds__(1024) void compact_targets_kernel(const int64_t* __
 // live rows stay contiguous and ordered: a ragged batch.  One workgroup of 1024 threads sweeps the [B,T] arrays
 // three times with coalesced loads; the per-sample lengths and offsets live in LDS.
 __global__ __launch_bounds__(1024) void compact_prefix_kernel(const int64_t* __restrict__ ids,
-                                                              const int64_t* __restrict__ targets, int B, int T,
+                                                              const int64_t* __restrict__ targets, int64_t ld, int B, int T,
                                                               int64_t pad, int64_t* __restrict__ order,
                                                               int64_t* __restrict__ slot, int32_t* __restrict__ seq_off,
                                                               int32_t* __restrict__ sample, int32_t* __restrict__ ids_c,
@@ -1446,11 +1484,13 @@ __global__ __launch_bounds__(1024) void compact_prefix_kernel(const int64_t* __r
         mark[b] = 0;
     }
     __syncthreads();
+    // (element (b, p) of ids and targets sits at b*ld + p: ld = T for packed arrays, T + 1 for the two views of a
+    //  [B, T+1] caption matrix)
     for (int r = t; r < M; r += 1024)
-        if (targets[r] != pad) atomicMax(&len[r / T], r % T + 1);
+        if (targets[(int64_t)(r / T) * ld + r % T] != pad) atomicMax(&len[r / T], r % T + 1);
     __syncthreads();
     for (int r = t; r < M; r += 1024)
-        if (ids[r] == pad && r % T < len[r / T]) mark[r / T] = 1;      // a <PAD> input inside the prefix
+        if (ids[(int64_t)(r / T) * ld + r % T] == pad && r % T < len[r / T]) mark[r / T] = 1;      // a <PAD> input inside the prefix
     __syncthreads();
     for (int b = t; b < B; b += 1024)
         if (mark[b]) len[b] = T;
@@ -1484,8 +1524,8 @@ __global__ __launch_bounds__(1024) void compact_prefix_kernel(const int64_t* __r
             const int s = off[b] + p;
             order[s] = r;
             sample[s] = b;
-            ids_c[s] = (int32_t)ids[r];
-            tgt_c[s] = targets[r];
+            ids_c[s] = (int32_t)ids[(int64_t)b * ld + p];
+            tgt_c[s] = targets[(int64_t)b * ld + p];
             slot[r] = s;
         } else {
             slot[r] = M;                          // the caller's all-zero extra row
@@ -1714,13 +1754,30 @@ int capdec_embed_bwd(const int64_t* ids, const float* dx, int rows, int E, int V
 
 int capdec_embed_bwd_rows(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb,
                           const int32_t* rows_dev, void* stream) {
-    CAPDEC_REQUIRE(ids && dx && demb && rows >= 0 && E >= 1 && V >= 1);
+    return capdec_embed_train_bwd(ids, dx, rows, E, V, 0.f, 0, nullptr, demb, rows_dev, stream);
+}
+
+int capdec_embed_train_fwd(const int64_t* ids, int64_t ldid, const int64_t* order, const float* emb, const float* pe, int M,
+                           int T, int E, int V, float p, uint64_t seed, const uint64_t* seed_dev, float* x, int64_t* ids_out,
+                           void* stream) {
+    CAPDEC_REQUIRE(ids && emb && x && M >= 0 && T >= 1 && ldid >= T && E >= 4 && E % 4 == 0 && V >= 1 && p >= 0.f && p < 1.f);
+    if (!capdec_aligned16(emb) || !capdec_aligned16(x) || (pe && !capdec_aligned16(pe))) return CAPDEC_EALIGN;
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(embed_train_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, ldid, order, emb, pe,
+                       M, T, E, V, p, seed, seed_dev, x, ids_out);
+    CAPDEC_LAUNCH_CHECK();
+    return 0;
+}
+
+int capdec_embed_train_bwd(const int64_t* ids, const float* dx, int rows, int E, int V, float p, uint64_t seed,
+                           const uint64_t* seed_dev, float* demb, const int32_t* rows_dev, void* stream) {
+    CAPDEC_REQUIRE(ids && dx && demb && rows >= 0 && E >= 1 && V >= 1 && p >= 0.f && p < 1.f);
     if (rows == 0) return 0;
     CAPDEC_REQUIRE((size_t)EB_HOT * E * sizeof(float) <= 60 * 1024);
     int per = (rows + 255) / 256;                      // about one workgroup per CU before the rows per workgroup grow
     per = per < 8 ? 8 : (per > 64 ? 64 : (per + 3) / 4 * 4);
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + per - 1) / per), dim3(256), EB_HOT * E * sizeof(float),
-                       (hipStream_t)stream, ids, dx, rows, E, V, demb, rows_dev, per);
+                       (hipStream_t)stream, ids, dx, rows, E, V, demb, rows_dev, per, p, seed, seed_dev);
     CAPDEC_LAUNCH_CHECK();
     return 0;
 }
@@ -1955,14 +2012,21 @@ int capdec_compact_targets(const int64_t* targets, int M, int64_t ignore_index, 
 int capdec_compact_prefix(const int64_t* ids, const int64_t* targets, int B, int T, int64_t pad, int64_t* order,
                           int64_t* slot, int32_t* seq_off, int32_t* sample, int32_t* ids_c, int64_t* targets_c,
                           int32_t* count, void* stream) {
+    return capdec_compact_prefix_strided(ids, targets, T, B, T, pad, order, slot, seq_off, sample, ids_c, targets_c, count,
+                                         stream);
+}
+
+int capdec_compact_prefix_strided(const int64_t* ids, const int64_t* targets, int64_t ld, int B, int T, int64_t pad,
+                                  int64_t* order, int64_t* slot, int32_t* seq_off, int32_t* sample, int32_t* ids_c,
+                                  int64_t* targets_c, int32_t* count, void* stream) {
     CAPDEC_REQUIRE(ids && targets && order && slot && seq_off && sample && ids_c && targets_c && count);
-    CAPDEC_REQUIRE(B >= 1 && T >= 1 && (int64_t)B * T < INT_MAX);
+    CAPDEC_REQUIRE(B >= 1 && T >= 1 && ld >= T && (int64_t)B * T < INT_MAX);
     const size_t smem = ((size_t)3 * B + 1024) * sizeof(int);
     CAPDEC_REQUIRE(smem <= 144 * 1024);           // B <= 11946: the per-sample bookkeeping lives in LDS
     static const bool ready = hipFuncSetAttribute(reinterpret_cast<const void*>(compact_prefix_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess;
     if (!ready) return CAPDEC_EINVAL;
-    hipLaunchKernelGGL(compact_prefix_kernel, dim3(1), dim3(1024), smem, (hipStream_t)stream, ids, targets, B, T, pad,
+    hipLaunchKernelGGL(compact_prefix_kernel, dim3(1), dim3(1024), smem, (hipStream_t)stream, ids, targets, ld, B, T, pad,
                        order, slot, seq_off, sample, ids_c, targets_c, count);
     CAPDEC_LAUNCH_CHECK();
     return 0;

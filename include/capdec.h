@@ -322,6 +322,17 @@ int capdec_embed_bwd(const int64_t* ids, const float* dx, int rows, int E, int V
 /* The same over the first min(rows, rows_dev[0]) rows (rows_dev: nullable device scalar). */
 int capdec_embed_bwd_rows(const int64_t* ids, const float* dx, int rows, int E, int V, float* demb,
                           const int32_t* rows_dev, void* stream);
+/* Embedding + positional encoding + dropout of a training step in one launch (transformer.py:126 with self.dropout in
+ * training mode): x[s,:] = dropout(emb[id,:] + pe[i,:]) for the M slots s, where slot s is dense row r = order[s]
+ * (order nullable: r = s) = position i = r % T of sample r / T, and its id is ids[(r / T)*ldid + i] (ldid >= T: the
+ * ids may be a view of a wider matrix, e.g. captions[:, :-1]).  The mask is the one capdec_dropout draws for element
+ * s*E + c of x (same seed, seed_dev).  ids_out (nullable) [M] receives the slots' ids.  pe nullable. */
+int capdec_embed_train_fwd(const int64_t* ids, int64_t ldid, const int64_t* order, const float* emb, const float* pe, int M,
+                           int T, int E, int V, float p, uint64_t seed, const uint64_t* seed_dev, float* x, int64_t* ids_out,
+                           void* stream);
+/* Its backward: capdec_embed_bwd_rows on dropout(dx) with that same mask, without the launch in between. */
+int capdec_embed_train_bwd(const int64_t* ids, const float* dx, int rows, int E, int V, float p, uint64_t seed,
+                           const uint64_t* seed_dev, float* demb, const int32_t* rows_dev, void* stream);
 int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma, const float* save_mean,
                              const float* save_rstd, int B, int C, float* dx, float* dgamma, float* dbeta,
                              void* stream);
@@ -376,6 +387,11 @@ int capdec_compact_targets(const int64_t* targets, int M, int64_t ignore_index, 
 int capdec_compact_prefix(const int64_t* ids, const int64_t* targets, int B, int T, int64_t pad, int64_t* order,
                           int64_t* slot, int32_t* seq_off, int32_t* sample, int32_t* ids_c, int64_t* targets_c,
                           int32_t* count, void* stream);
+/* The same with element (b, p) of ids and targets at b*ld + p (ld >= T): the inputs captions[:, :-1] and the targets
+ * captions[:, 1:] of train.py:253-256 as two views (ld = T + 1) of the caption matrix, without a copy of either. */
+int capdec_compact_prefix_strided(const int64_t* ids, const int64_t* targets, int64_t ld, int B, int T, int64_t pad,
+                                  int64_t* order, int64_t* slot, int32_t* seq_off, int32_t* sample, int32_t* ids_c,
+                                  int64_t* targets_c, int32_t* count, void* stream);
 /* sums = (sum of nll, number of counted targets) from capdec_nll_finalize:
  * loss[0] = sums[0] / sums[1] (nn.CrossEntropyLoss mean over non-ignored targets), gscale[0] = 1 / sums[1] */
 int capdec_loss_finish(const float* sums, float* loss, float* gscale, void* stream);

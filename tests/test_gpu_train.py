@@ -404,6 +404,60 @@ def test_compaction_maps_against_a_python_restatement(B, T, seed):
     assert s2.cpu().tolist() == want_slot
 
 
+@pytest.mark.parametrize("B,T", [(1, 1), (9, 7), (64, 20)])
+def test_compaction_reads_the_two_views_of_a_caption_matrix_in_place(B, T):
+    """capdec_compact_prefix_strided on captions[:, :-1] / captions[:, 1:] (row stride T + 1, train.py:253-256) gives
+    every array of the packed call."""
+    from capdec import ops
+    g = torch.Generator().manual_seed(B * 31 + T)
+    caps = torch.randint(0, 5, (B, T + 1), generator=g)
+    for b in range(0, B, 2):
+        n = int(torch.randint(0, T + 2, (1,), generator=g))
+        caps[b, n:] = 0
+    caps = caps.cuda()
+    a = ops.RaggedRows(caps[:, :-1], caps[:, 1:], 0)
+    b_ = ops.RaggedRows(caps[:, :-1].contiguous(), caps[:, 1:].contiguous(), 0)
+    live = int(b_.counts[1])
+    for name in ("order", "slot", "seq_off", "sample", "ids_c", "targets_c", "counts"):
+        assert torch.equal(getattr(a, name), getattr(b_, name)), name
+    assert live <= B * T
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_embedding_position_dropout_in_one_launch(p, ragged):
+    """capdec_embed_train_fwd / _bwd against the launches they replace (embedding + position, move to the slots,
+    dropout; dropout, scatter-add): bit for bit forward, and backward up to the order of the float atomics."""
+    from capdec import ops
+    B, T, E, V = 37, 11, 64, 50
+    g = torch.Generator().manual_seed(5)
+    caps = torch.randint(0, V, (B, T + 1), generator=g).cuda()
+    emb = torch.randn(V, E, generator=g).cuda()
+    pe = torch.randn(T + 3, E, generator=g).cuda()
+    seed = 0x1234567
+    seed_dev = torch.tensor([99], dtype=torch.int64, device="cuda")
+    ids = caps[:, :-1]
+    order = torch.randperm(B * T, generator=g).cuda() if ragged else None
+    x, ids_out = ops.embed_train(ids, emb, pe, p, seed, seed_dev=seed_dev, order=order, want_ids=True)
+    want = ops.embed_pe(ids.contiguous(), emb, pe)
+    flat_ids = ids.contiguous().view(-1)
+    if ragged:
+        want = want.index_select(0, order)
+        flat_ids = flat_ids.index_select(0, order)
+    if p > 0:
+        want = ops.dropout(want, p, seed, seed_dev=seed_dev)
+        assert 0.03 < float((x == 0).float().mean()) < 0.2
+    assert torch.equal(x, want) and torch.equal(ids_out, flat_ids)
+    # backward
+    dx = torch.randn(B * T, E, generator=g).cuda()
+    rows = torch.tensor([B * T - 5], dtype=torch.int32, device="cuda")
+    got = ops.embed_bwd(ids_out, dx, torch.zeros(V, E, device="cuda"), rows_dev=rows, p=p, seed=seed, seed_dev=seed_dev)
+    dxm = ops.dropout(dx, p, seed, seed_dev=seed_dev) if p > 0 else dx
+    ref = torch.zeros(V, E, dtype=torch.float64, device="cuda")
+    ref.index_add_(0, ids_out[:B * T - 5], dxm[:B * T - 5].double())
+    close(got, ref.cpu().numpy(), rtol=1e-6, what="embedding gradient")
+
+
 def test_f6_cnn_attn_train_mode_batchnorm_and_head_gradients():
     from models.cnnattn_model import CNNAttentionModel
     fx = load_golden("f6_heads")
