@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Prints the kernel timeline of the last complete step of a rocprofv3 --kernel-trace database (rocpd format):
-start offset, duration, gap to the previous kernel's end, stream, grid, name.  A step starts at `embed_pe_kernel`."""
+start offset, duration, gap to the previous kernel's end, stream, grid, name.  A step starts at `embed_train_fwd_kernel`."""
 import re
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-marker = sys.argv[2] if len(sys.argv) > 2 else "embed_pe"
+marker = sys.argv[2] if len(sys.argv) > 2 else "embed_train_fwd"
 tables = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
 sfx = [t for t in tables if t.startswith("rocpd_kernel_dispatch")][0][len("rocpd_kernel_dispatch"):]
 ks = {r[0]: r[1] for r in db.execute(f"select id, kernel_name from rocpd_info_kernel_symbol{sfx}")}

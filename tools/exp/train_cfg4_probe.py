@@ -9,5 +9,5 @@ sys.path.insert(0, ROOT)
 import torch
 import bench
 
-r = bench.train_bench(torch.device("cuda:0"), 0, 1, 4, 2, torch.cuda.synchronize, model_kind="vitcnn", layers=2)
+r = bench.train_bench(torch.device("cuda:0"), 0, 1, 20, 4, torch.cuda.synchronize, model_kind="vitcnn", layers=2)
 print(json.dumps({k: r[k] for k in ("value", "ms_per_step")}))
