@@ -70,6 +70,13 @@ int main() {
     EXPECT(capdec_embed_pe(al, 0, 4, a, a, 0, 2, 4, 6, 10, a, nullptr), CAPDEC_EINVAL);           // E % 4 != 0
     EXPECT(capdec_embed_pe(al, 0, 2, a, a, 0, 2, 4, 8, 10, a, nullptr), CAPDEC_EINVAL);           // ldid < T
     EXPECT(capdec_embed_pe(al, 0, 4, una, a, 0, 2, 4, 8, 10, a, nullptr), CAPDEC_EALIGN);
+    EXPECT(capdec_embed_train_fwd(al, 3, nullptr, a, a, 8, 4, 8, 10, 0.1f, 1, nullptr, a, nullptr, nullptr), CAPDEC_EINVAL);   // ldid < T
+    EXPECT(capdec_embed_train_fwd(al, 4, nullptr, a, a, 8, 4, 8, 10, 1.0f, 1, nullptr, a, nullptr, nullptr), CAPDEC_EINVAL);   // p must be < 1
+    EXPECT(capdec_embed_train_fwd(al, 4, nullptr, una, a, 8, 4, 8, 10, 0.f, 1, nullptr, a, nullptr, nullptr), CAPDEC_EALIGN);
+    EXPECT(capdec_embed_train_fwd(al, 4, nullptr, a, a, 0, 4, 8, 10, 0.f, 1, nullptr, a, nullptr, nullptr), 0);              // no slots: nothing launched
+    EXPECT(capdec_embed_train_bwd(nullptr, a, 4, 8, 10, 0.f, 1, nullptr, a, nullptr, nullptr), CAPDEC_EINVAL);
+    EXPECT(capdec_embed_train_bwd(al, a, 0, 8, 10, 0.5f, 1, nullptr, a, nullptr, nullptr), 0);
+    EXPECT(capdec_compact_prefix_strided(al, al, 3, 2, 4, 0, al, al, ai, ai, ai, al, ai, nullptr), CAPDEC_EINVAL);           // ld < T
     EXPECT(capdec_add_layernorm(nullptr, nullptr, 1, a, a, 1e-5f, 4, 64, a, nullptr, nullptr, nullptr), CAPDEC_EINVAL);
     EXPECT(capdec_attention(nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 1, 1, 1, 1, 64, 0, 0, nullptr, 0, nullptr,
                             nullptr), CAPDEC_EINVAL);
