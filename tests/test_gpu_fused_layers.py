@@ -199,3 +199,54 @@ def test_greedy_decode_enqueued_ahead_equals_the_synchronous_call():
         assert torch.equal(ids, want[0]) and torch.equal(lens, want[1]) and nd == want[2]
         redone += nd
     assert redone > 0
+
+
+def test_one_launch_layers_random_shapes_repeat_bit_for_bit_beside_other_work():
+    """A short form of tools/exp/fused_soak.py: random batch sizes (1 ... 2048 rows: one and two workgroups per CU,
+    several dispatch rounds), lengths, layer counts and memory rows; every decode is repeated beside bursts of large
+    contractions on a second stream and must give the same ids, lengths and final rows bit for bit; against the
+    launch-per-operation form only arg-max near-ties may differ."""
+    import random
+    from capdec.engine import tf_greedy_ids
+    rng = random.Random(7)
+    a = torch.randn(2048, 2048, device="cuda")
+    side = torch.cuda.Stream()
+    decs = {}
+    differing = rows = 0
+    for case in range(36):
+        L = rng.choice((1, 2, 2))
+        S = rng.choice((1, 1, 2))
+        V = rng.choice((500, 3000))
+        B = rng.choice((1, 7, 16, 17, 64, 100, 256, 513, 777, 1024, 1500, 2048))
+        ML = rng.choice((2, 5, 12, 20, 33, 50))
+        pad_bias = rng.choice((0.0, 0.8, 1.3))
+        key = (L, V, pad_bias)
+        if key not in decs:
+            torch.manual_seed(200 + len(decs))
+            d = plain_decoder(E, V, H, L, max_len=50).cuda().eval()
+            with torch.no_grad():
+                d.fc2.bias[R.PAD] += pad_bias
+            decs[key] = d
+        dec = decs[key]
+        g = torch.Generator().manual_seed(case)
+        enc = torch.randn(B, S, E, generator=g).cuda()
+        w0, w1 = [], []
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            ids0, len0, nd0 = tf_greedy_ids(dec, enc, ML, R.SOS, R.EOS, keep_workspace=w0)
+            torch.cuda.synchronize()
+            x0 = w0[0][:B * E * 4].clone()
+            with torch.cuda.stream(side):
+                for _ in range(rng.randint(1, 6)):
+                    a @ a
+            ids1, len1, nd1 = tf_greedy_ids(dec, enc, ML, R.SOS, R.EOS, keep_workspace=w1)
+            torch.cuda.synchronize()
+            idp, lenp, _ = tf_greedy_ids(dec, enc, ML, R.SOS, R.EOS, fused_layers=False)
+        what = (case, L, S, V, B, ML, pad_bias)
+        assert torch.equal(ids0, ids1) and torch.equal(len0, len1) and nd0 == nd1, what
+        assert torch.equal(w1[0][:B * E * 4], x0), what
+        d = int(((ids0 != idp).any(dim=1) | (len0 != lenp)).sum())
+        assert d <= max(2, B // 100), what + (d,)
+        differing += d
+        rows += B
+    assert differing <= rows // 2000 + 2, (differing, rows)
