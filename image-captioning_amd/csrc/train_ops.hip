@@ -1028,6 +1028,200 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnBwdArgs a) {
     }
 }
 
+// The same for the caption decoder's own shape -- head width 128, at most 32 positions, a ragged batch -- on the matrix
+// cores.  The five contractions of a (sample, head) are 32 x 32 x 128 (scores S = Q K^T, dP = dO V^T) and 32 x 128 x 32
+// (dQ = dS K, dK = dS^T Q, dV = P^T dO) when the sample's T <= 32 rows are padded to 32 (the padding's probabilities
+// are forced to zero): 640 fp32 MFMAs of 16 x 16 x 4 instead of row-by-row dot products and shuffles; every operand is
+// read from memory once and the three gradients leave as 16-byte stores.  One workgroup of four wavefronts per
+// (sample, head):
+//   stage 1: wavefront w owns the 16 x 16 tile (w >> 1, w & 1) of S and of dP; probabilities from the saved
+//            log-sum-exp, the row sums D_i = sum_j P_ij dP_ij of the two column tiles meet in LDS, dS = P (dP - D);
+//   stage 2: wavefront w owns the head columns [32w, 32w + 32) of dQ, dK, dV.
+// Operand layout (v_mfma_f32_16x16x4_f32): lane (c, g) = (lane & 15, lane >> 4) feeds A[row c][k = 4g' + m] and
+// B[k][column c] of MFMA m; accumulator register e of lane (c, g) is row 4g + e, column c.  Q, dO, K, V rows are padded
+// to 132 floats and P, dS rows to 36: every 16-byte or 4-byte fragment read of 64 lanes falls on distinct banks.
+constexpr int ABM_T = 32, ABM_DK = 128, ABM_LD = ABM_DK + 4, ABM_PL = ABM_T + 4;
+// rows = the launch's T (the longest possible sample): LDS holds that many rows of Q, dO, K, V; the fragment reads of the
+// rows from there up to 32 are clamped to the last one (any finite values do: their probabilities are zero)
+static size_t abm_lds_bytes(int rows) {
+    return ((size_t)4 * rows * ABM_LD + 2 * ABM_T * ABM_PL + 2 * ABM_T) * sizeof(float);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int R = a.Tq;                       // rows held per operand
+    float* Qs = lds;
+    float* Os = Qs + R * ABM_LD;
+    float* Ks = Os + R * ABM_LD;
+    float* Vs = Ks + R * ABM_LD;
+    float* Ps = Vs + R * ABM_LD;              // [32][36] probabilities
+    float* Ds = Ps + ABM_T * ABM_PL;          // [32][36] dS
+    float* Dp = Ds + ABM_T * ABM_PL;          // [2][32] row sums of P dP per column tile
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int64_t q0 = a.seq_off[b];
+    const int T = min(a.Tq, a.seq_off[b + 1] - a.seq_off[b]);          // this sample's rows: queries and keys
+    const int64_t hc = (int64_t)h * ABM_DK;
+    const int ti = wave >> 1, tj = wave & 1;
+    // the log-sum-exp and the <PAD> flag of this lane's four query rows, in flight with the operand rows
+    float lse_r[4];
+    int pad_r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = ti * 16 + 4 * g + e;
+        lse_r[e] = i < T ? a.lse[((int64_t)b * a.H + h) * a.Tq + i] : 0.f;
+        pad_r[e] = (i < T && a.ids) ? (a.ids[q0 + i] == 0) : 0;
+    }
+    // ---- stage 0: this head's columns of the sample's rows; the rows from T on are zero ---------------------------
+    for (int idx = threadIdx.x; idx < R * (ABM_DK / 4); idx += 256) {
+        const int r = idx >> 5, v4 = (idx & 31) * 4;
+        f32x4 xq = {0.f, 0.f, 0.f, 0.f}, xo = xq, xk = xq, xv = xq;
+        if (r < T) {
+            xq = *reinterpret_cast<const f32x4*>(a.q + (q0 + r) * a.ldq + hc + v4);
+            xo = *reinterpret_cast<const f32x4*>(a.dout + (q0 + r) * a.ldo + hc + v4);
+            xk = *reinterpret_cast<const f32x4*>(a.k + (q0 + r) * a.ldk + hc + v4);
+            xv = *reinterpret_cast<const f32x4*>(a.v + (q0 + r) * a.ldv + hc + v4);
+        }
+        *reinterpret_cast<f32x4*>(Qs + r * ABM_LD + v4) = xq;
+        *reinterpret_cast<f32x4*>(Os + r * ABM_LD + v4) = xo;
+        *reinterpret_cast<f32x4*>(Ks + r * ABM_LD + v4) = xk;
+        *reinterpret_cast<f32x4*>(Vs + r * ABM_LD + v4) = xv;
+    }
+    __syncthreads();
+    // ---- stage 1: S and dP tiles, probabilities, dS -------------------------------------------------------------
+    const float scale = sqrtf((float)ABM_DK);
+    f32x4 accs = {0.f, 0.f, 0.f, 0.f}, accp = accs;
+    {
+        const int ra = min(ti * 16 + c, R - 1), rb = min(tj * 16 + c, R - 1);
+        const float* qa = Qs + ra * ABM_LD + 4 * g;
+        const float* oa = Os + ra * ABM_LD + 4 * g;
+        const float* kb = Ks + rb * ABM_LD + 4 * g;
+        const float* vb = Vs + rb * ABM_LD + 4 * g;
+#pragma unroll
+        for (int kc = 0; kc < ABM_DK / 16; ++kc) {
+            const f32x4 fq = *reinterpret_cast<const f32x4*>(qa + 16 * kc);
+            const f32x4 fk = *reinterpret_cast<const f32x4*>(kb + 16 * kc);
+            const f32x4 fo = *reinterpret_cast<const f32x4*>(oa + 16 * kc);
+            const f32x4 fv = *reinterpret_cast<const f32x4*>(vb + 16 * kc);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                accs = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[m], fk[m], accs, 0, 0, 0);
+                accp = __builtin_amdgcn_mfma_f32_16x16x4f32(fo[m], fv[m], accp, 0, 0, 0);
+            }
+        }
+    }
+    f32x4 pr;
+    {
+        const int j = tj * 16 + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = ti * 16 + 4 * g + e;
+            float pe = 0.f, pd = 0.f;
+            if (i < T) {
+                if (pad_r[e]) {
+                    // every score is the same fill value: uniform over all T keys, independent of q and k (dS = 0)
+                    pe = j < T ? 1.0f / (float)T : 0.f;
+                } else {
+                    int nkeys = T;
+                    if (a.causal) {
+                        nkeys = i + a.causal_off + 1;
+                        nkeys = nkeys < 1 ? 1 : (nkeys > T ? T : nkeys);
+                    }
+                    if (j < nkeys) {
+                        pe = expf(accs[e] / scale - lse_r[e]);
+                        pd = pe * accp[e];
+                    }
+                }
+            }
+            pr[e] = pe;
+            // the row's sum over this tile's 16 columns: lanes with the same g
+            pd += __shfl_xor(pd, 1, 64);
+            pd += __shfl_xor(pd, 2, 64);
+            pd += __shfl_xor(pd, 4, 64);
+            pd += __shfl_xor(pd, 8, 64);
+            if (c == 0) Dp[tj * ABM_T + i] = pd;
+        }
+    }
+    __syncthreads();
+    {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = ti * 16 + 4 * g + e;
+            const float D = Dp[i] + Dp[ABM_T + i];
+            const float ds = (pad_r[e] || pr[e] == 0.f) ? 0.f : pr[e] * (accp[e] - D);
+            Ps[i * ABM_PL + tj * 16 + c] = pr[e];
+            Ds[i * ABM_PL + tj * 16 + c] = ds;
+        }
+    }
+    __syncthreads();
+    // ---- stage 2: dQ = dS K / sqrt(dk), dK = dS^T Q / sqrt(dk), dV = P^T dO; this wavefront's 32 head columns ------
+    const float inv = 1.0f / scale;
+    f32x4 aq[2][2], ak[2][2], av[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {                   // the two 16-row tiles of the outputs
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) aq[rt][ct] = ak[rt][ct] = av[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rt * 16 >= T) break;                       // (uniform: rows that are not stored)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {               // contraction over the 32 keys (dQ) or queries (dK, dV)
+            if (kc * 16 >= T) break;                   // (uniform: nothing but zeros from here on)
+            // dQ: A = dS[rt*16 + c][kc*16 + 4g + m]
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(Ds + (rt * 16 + c) * ABM_PL + kc * 16 + 4 * g);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int kk = kc * 16 + 4 * g + m;    // the contraction index this lane feeds to MFMA m
+                const int kr = min(kk, R - 1);
+                // dK, dV: A = dS^T, P^T: [key rt*16 + c][query kk]
+                const float fds = Ds[kk * ABM_PL + rt * 16 + c];
+                const float fp = Ps[kk * ABM_PL + rt * 16 + c];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int d = wave * 32 + ct * 16 + c;
+                    aq[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m], Ks[kr * ABM_LD + d], aq[rt][ct], 0, 0, 0);
+                    ak[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(fds, Qs[kr * ABM_LD + d], ak[rt][ct], 0, 0, 0);
+                    av[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp, Os[kr * ABM_LD + d], av[rt][ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                                   // every wavefront is done reading Q, dO, K
+    // the three gradients through LDS (over Q, K, dO: rows of 132 floats again), so that they leave as 16-byte stores
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = rt * 16 + 4 * g + e;
+                if (r < T) {
+                    const int col = wave * 32 + ct * 16 + c;
+                    Qs[r * ABM_LD + col] = aq[rt][ct][e] * inv;
+                    Ks[r * ABM_LD + col] = ak[rt][ct][e] * inv;
+                    Os[r * ABM_LD + col] = av[rt][ct][e];
+                }
+            }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T * (ABM_DK / 4); idx += 256) {
+        const int r = idx >> 5, v4 = (idx & 31) * 4;
+        *reinterpret_cast<f32x4*>(a.dq + (q0 + r) * a.lddq + hc + v4) = *reinterpret_cast<const f32x4*>(Qs + r * ABM_LD + v4);
+        *reinterpret_cast<f32x4*>(a.dk + (q0 + r) * a.lddk + hc + v4) = *reinterpret_cast<const f32x4*>(Ks + r * ABM_LD + v4);
+        *reinterpret_cast<f32x4*>(a.dv + (q0 + r) * a.lddv + hc + v4) = *reinterpret_cast<const f32x4*>(Os + r * ABM_LD + v4);
+    }
+    if (b == a.B - 1) {
+        // the slots between the last sample and the next multiple of 32 belong to no sample but are read by the
+        // contractions that follow: this head's columns of those gradient rows are zeroed here
+        const int live = a.seq_off[a.B], upto = min(a.B * a.Tq, (live + 31) / 32 * 32);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int idx = threadIdx.x; idx < (upto - live) * (ABM_DK / 4); idx += 256) {
+            const int r = live + idx / (ABM_DK / 4), v4 = (idx % (ABM_DK / 4)) * 4;
+            *reinterpret_cast<f32x4*>(a.dq + (int64_t)r * a.lddq + hc + v4) = z;
+            *reinterpret_cast<f32x4*>(a.dk + (int64_t)r * a.lddk + hc + v4) = z;
+            *reinterpret_cast<f32x4*>(a.dv + (int64_t)r * a.lddv + hc + v4) = z;
+        }
+    }
+}
+
 // Long memory, short query block (cross-attention over a token or grid memory: Tq <= 64, any Tk, no mask): one
 // workgroup per (b,h) keeps Q, dO and a dQ accumulator in LDS and streams the keys through LDS in chunks of AB_KC.
 // D_i = sum_j P_ij dP_ij equals dO_i . O_i, so with the forward output at hand every chunk is independent: its P and
@@ -1793,9 +1987,14 @@ int capdec_bn_train_backward(const float* dy, const float* x, const float* gamma
 }
 
 static CAPDEC_HOOK_VAR(g_attn_bwd_two_pass);
+static CAPDEC_HOOK_VAR(g_attn_bwd_rows);
 #ifdef CAPDEC_TUNING_HOOKS
 int capdec_attention_bwd_force_two_pass(int on) {
     g_attn_bwd_two_pass = on ? 1 : 0;
+    return 0;
+}
+int capdec_attention_bwd_force_row_form(int on) {
+    g_attn_bwd_rows = on ? 1 : 0;
     return 0;
 }
 #endif
@@ -1815,6 +2014,16 @@ int capdec_attention_bwd_ragged(const float* q, int64_t ldq, const float* k, int
     CAPDEC_REQUIRE(fused_lds <= 144 * 1024);
     AttnBwdArgs a{q, ldq, k, ldk, 0, v, ldv, 0, dout, ldo, nullptr, 0, lse, nullptr, dq, lddq, dk, lddk, 0, dv, lddv, 0,
                   B, H, T, T, dkh, 1, 0, ids, 0, seq_off, 0};
+    if (dkh == ABM_DK && T <= ABM_T && !g_attn_bwd_two_pass && !g_attn_bwd_rows) {
+        // the caption decoder's own shape: the five contractions of a (sample, head) on the matrix cores
+        static const bool ready_m = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)abm_lds_bytes(ABM_T)) == hipSuccess;
+        if (!ready_m) return CAPDEC_EINVAL;
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)(B * H)), dim3(256), abm_lds_bytes(T), (hipStream_t)stream, a);
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
     static const bool ready = [] {
         bool ok = true;
 #define CAPDEC_CALL(NM_)                                                                                    \

@@ -26,6 +26,9 @@ int capdec_lstm_force_staging(int mode);
 /* non-zero: attention backward always takes the general two-pass kernels (sequences up to 64 positions normally take a
  * one-pass kernel that keeps a (batch, head) slice in LDS) */
 int capdec_attention_bwd_force_two_pass(int on);
+/* non-zero: the self-attention backward of a ragged batch keeps the row-by-row one-pass kernel where the matrix-core
+ * form (head width 128, at most 32 positions) would be taken */
+int capdec_attention_bwd_force_row_form(int on);
 /* non-zero: long unmasked memories (more than 64 keys) stay on the one-wavefront-per-row forward kernel instead of the
  * chunked one */
 int capdec_attention_force_row_kernel(int on);

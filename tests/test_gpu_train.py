@@ -884,6 +884,64 @@ def test_attention_backward_one_pass_matches_two_pass(B, H, Tq, Tk, dk, causal, 
         close(a, b.cpu().numpy(), rtol=1e-5, what=name)
 
 
+@pytest.mark.parametrize("B,T,H", [(1, 1, 1), (9, 20, 4), (33, 32, 2), (64, 7, 4)])
+def test_ragged_self_attention_backward_on_the_matrix_cores(B, T, H, tuning_lib):
+    """Head width 128, at most 32 positions (the caption decoder's own shape): the MFMA form of the ragged self-attention
+    backward against the row-by-row one-pass kernel and against fp64 arithmetic (transformer.py:18-27 differentiated by
+    hand: causal rows, <PAD> query rows uniform over the sample's keys), on ragged batches with empty samples."""
+    from capdec import ops
+    dk = 128
+    E = H * dk
+    g = torch.Generator().manual_seed(B * 7 + T)
+    ids = torch.randint(1, 6, (B, T), generator=g)
+    tgt = torch.randint(1, 3, (B, T), generator=g)
+    for b in range(B):
+        n = int(torch.randint(0, T + 1, (1,), generator=g))
+        tgt[b, n:] = 0
+        ids[b, n:] = 0
+        if n > 2 and b % 3 == 0:
+            ids[b, n // 2] = 0                           # a <PAD> input inside the prefix: the sample keeps all T rows
+    rr = ops.RaggedRows(ids.cuda(), tgt.cuda(), 0)
+    M = B * T
+    q, k, v, do = (torch.randn(M, E, generator=g).cuda() for _ in range(4))
+    o, lse = ops.attention_ragged(q, k, v, rr, H, want_lse=True)
+    got = ops.attention_bwd_ragged(q, k, v, do, lse, rr, H)
+    tuning_lib.capdec_attention_bwd_force_row_form(1)
+    try:
+        rows = ops.attention_bwd_ragged(q, k, v, do, lse, rr, H)
+    finally:
+        tuning_lib.capdec_attention_bwd_force_row_form(0)
+    live = int(rr.counts[1])
+    up = int(rr.counts[0])
+    for a_, b_, name in zip(got, rows, ("dq", "dk", "dv")):
+        close(a_[:up], b_[:up].cpu().numpy(), rtol=2e-6, what=name + " vs the row form")
+        assert float(a_[live:up].abs().max()) == 0.0 if up > live else True
+    # fp64, sample by sample
+    off = rr.seq_off.cpu().tolist()
+    idc = rr.ids_c.cpu()
+    want = [torch.zeros(M, E, dtype=torch.float64) for _ in range(3)]
+    q64, k64, v64, do64 = (x.double().cpu() for x in (q, k, v, do))
+    for b in range(B):
+        s0, s1 = off[b], off[b + 1]
+        n = s1 - s0
+        if n == 0:
+            continue
+        for h in range(H):
+            cs = slice(h * dk, (h + 1) * dk)
+            qq = q64[s0:s1, cs].clone().requires_grad_(True)
+            kk = k64[s0:s1, cs].clone().requires_grad_(True)
+            vv = v64[s0:s1, cs].clone().requires_grad_(True)
+            sc = qq @ kk.t() / dk ** 0.5
+            mask = torch.tril(torch.ones(n, n, dtype=torch.bool))
+            mask[idc[s0:s1] == 0, :] = False
+            sc = sc.masked_fill(~mask, -1e9)
+            out = torch.softmax(sc, dim=-1) @ vv
+            out.backward(do64[s0:s1, cs])
+            want[0][s0:s1, cs], want[1][s0:s1, cs], want[2][s0:s1, cs] = qq.grad, kk.grad, vv.grad
+    for a_, w_, name in zip(got, want, ("dq", "dk", "dv")):
+        close(a_[:live], w_[:live].numpy(), rtol=1e-5, what=name + " vs fp64")
+
+
 def test_checkpoint_roundtrip_resumes_training_exactly(tmp_path):
     """Save after two steps in the reference's checkpoint schema, load into a fresh model + trainer, take one more
     step on both: weights, Adam moments and step counter must carry over (dropout off, so steps are deterministic
