@@ -89,6 +89,14 @@ def main():
     o, lse = ops.attention(q, k, v, Bt, H, Tt, Tt, causal=True, ids32=ids32, want_lse=True)
     hbm("attn_bwd_fused_kernel", "B=512,H=4,T=20", 7.0 * Mt * E * 4,
         lambda: ops.attention_bwd(q, k, v, dy, lse, Bt, H, Tt, Tt, causal=True, ids32=ids32))
+    # the forms the trainer takes: the same batch as a ragged one (every row live here)
+    ids64 = ids32.to(torch.int64)
+    rr = ops.RaggedRows(ids64, ids64, 0)
+    hbm("attention_short_kernel (ragged batch: the trainer's forward)", "B=512,H=4,T=20", 4.0 * Mt * E * 4,
+        lambda: ops.attention_ragged(q, k, v, rr, H, want_lse=True))
+    _, lse_r = ops.attention_ragged(q, k, v, rr, H, want_lse=True)
+    hbm("attn_bwd_mfma_kernel (ragged batch: the trainer's backward, matrix cores)", "B=512,H=4,T=20", 7.0 * Mt * E * 4,
+        lambda: ops.attention_bwd_ragged(q, k, v, dy, lse_r, rr, H))
     St = 197
     km, vm = rnd(Bt * St, E), rnd(Bt * St, E)
     o2, lse2 = ops.attention(q, km, vm, Bt, H, Tt, St, want_lse=True)
