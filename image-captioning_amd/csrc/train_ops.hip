@@ -1060,8 +1060,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-    const int64_t q0 = a.seq_off[b];
-    const int T = min(a.Tq, a.seq_off[b + 1] - a.seq_off[b]);          // this sample's rows: queries and keys
+    // a ragged batch (seq_off): the sample's rows are slots q0 ... q0 + T - 1 of every operand; a dense one: T = Tq = Tk
+    // rows per sample, keys / values / their gradients at their own sample strides, ids [B, ldid]
+    const int64_t q0 = a.seq_off ? a.seq_off[b] : (int64_t)b * a.Tq;
+    const int T = a.seq_off ? min(a.Tq, a.seq_off[b + 1] - a.seq_off[b]) : a.Tq;      // this sample's rows: queries and keys
+    const int64_t id0 = a.seq_off ? q0 : (int64_t)b * a.ldid;
+    const float* kp = a.seq_off ? a.k + q0 * a.ldk : a.k + (int64_t)b * a.sk;
+    const float* vp = a.seq_off ? a.v + q0 * a.ldv : a.v + (int64_t)b * a.sv;
+    float* dkp = a.seq_off ? a.dk + q0 * a.lddk : a.dk + (int64_t)b * a.sdk;
+    float* dvp = a.seq_off ? a.dv + q0 * a.lddv : a.dv + (int64_t)b * a.sdv;
     const int64_t hc = (int64_t)h * ABM_DK;
     const int ti = wave >> 1, tj = wave & 1;
     // the log-sum-exp and the <PAD> flag of this lane's four query rows, in flight with the operand rows
@@ -1071,7 +1078,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
     for (int e = 0; e < 4; ++e) {
         const int i = ti * 16 + 4 * g + e;
         lse_r[e] = i < T ? a.lse[((int64_t)b * a.H + h) * a.Tq + i] : 0.f;
-        pad_r[e] = (i < T && a.ids) ? (a.ids[q0 + i] == 0) : 0;
+        pad_r[e] = (i < T && a.ids) ? (a.ids[id0 + i] == 0) : 0;
     }
     // ---- stage 0: this head's columns of the sample's rows; the rows from T on are zero ---------------------------
     for (int idx = threadIdx.x; idx < R * (ABM_DK / 4); idx += 256) {
@@ -1080,8 +1087,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
         if (r < T) {
             xq = *reinterpret_cast<const f32x4*>(a.q + (q0 + r) * a.ldq + hc + v4);
             xo = *reinterpret_cast<const f32x4*>(a.dout + (q0 + r) * a.ldo + hc + v4);
-            xk = *reinterpret_cast<const f32x4*>(a.k + (q0 + r) * a.ldk + hc + v4);
-            xv = *reinterpret_cast<const f32x4*>(a.v + (q0 + r) * a.ldv + hc + v4);
+            xk = *reinterpret_cast<const f32x4*>(kp + (int64_t)r * a.ldk + hc + v4);
+            xv = *reinterpret_cast<const f32x4*>(vp + (int64_t)r * a.ldv + hc + v4);
         }
         *reinterpret_cast<f32x4*>(Qs + r * ABM_LD + v4) = xq;
         *reinterpret_cast<f32x4*>(Os + r * ABM_LD + v4) = xo;
@@ -1205,10 +1212,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnBwdArgs a) {
     for (int idx = threadIdx.x; idx < T * (ABM_DK / 4); idx += 256) {
         const int r = idx >> 5, v4 = (idx & 31) * 4;
         *reinterpret_cast<f32x4*>(a.dq + (q0 + r) * a.lddq + hc + v4) = *reinterpret_cast<const f32x4*>(Qs + r * ABM_LD + v4);
-        *reinterpret_cast<f32x4*>(a.dk + (q0 + r) * a.lddk + hc + v4) = *reinterpret_cast<const f32x4*>(Ks + r * ABM_LD + v4);
-        *reinterpret_cast<f32x4*>(a.dv + (q0 + r) * a.lddv + hc + v4) = *reinterpret_cast<const f32x4*>(Os + r * ABM_LD + v4);
+        *reinterpret_cast<f32x4*>(dkp + (int64_t)r * a.lddk + hc + v4) = *reinterpret_cast<const f32x4*>(Ks + r * ABM_LD + v4);
+        *reinterpret_cast<f32x4*>(dvp + (int64_t)r * a.lddv + hc + v4) = *reinterpret_cast<const f32x4*>(Os + r * ABM_LD + v4);
     }
-    if (b == a.B - 1) {
+    if (a.seq_off && b == a.B - 1) {
         // the slots between the last sample and the next multiple of 32 belong to no sample but are read by the
         // contractions that follow: this head's columns of those gradient rows are zeroed here
         const int live = a.seq_off[a.B], upto = min(a.B * a.Tq, (live + 31) / 32 * 32);
@@ -2127,6 +2134,16 @@ int capdec_attention_bwd(const float* q, int64_t ldq, const float* k, int64_t ld
     AttnBwdArgs a{q, ldq, k, ldk, sk, v, ldv, sv, dout, ldo, out, ldout, lse, dsum, dq, lddq, dk, lddk, sdk, dv, lddv, sdv,
                   B, H, Tq, Tk, dkh, causal, causal_off, ids, ldid};
     hipStream_t s = (hipStream_t)stream;
+    if (dkh == ABM_DK && Tq == Tk && Tq <= ABM_T && !g_attn_bwd_two_pass && !g_attn_bwd_rows) {
+        // self-attention at the caption decoder's own shape: on the matrix cores (see attn_bwd_mfma_kernel)
+        static const bool ready_m = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)abm_lds_bytes(ABM_T)) == hipSuccess;
+        if (!ready_m) return CAPDEC_EINVAL;
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)(B * H)), dim3(256), abm_lds_bytes(Tq), s, a);
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
     // short sequences: everything of one (b,h) fits in LDS
     const size_t fused_lds = ((size_t)2 * (Tq + Tk) * (dkh + 16) + (size_t)2 * Tq * Tk) * sizeof(float);
     if (Tq <= 64 && Tk <= 64 && fused_lds <= 144 * 1024 && !g_attn_bwd_two_pass) {

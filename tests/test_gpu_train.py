@@ -856,7 +856,7 @@ def test_cnn_rnn_trainer_matches_oracle_training_loop(graph):
                 assert float(d.mean()) <= 3e-6, (k, float(d.mean()))
 
 
-@pytest.mark.parametrize("B,H,Tq,Tk,dk,causal", [(5, 4, 20, 20, 128, True), (3, 2, 7, 5, 16, False), (2, 4, 50, 50, 128, True),
+@pytest.mark.parametrize("B,H,Tq,Tk,dk,causal", [(5, 4, 20, 20, 128, True), (3, 4, 32, 32, 128, False), (3, 2, 7, 5, 16, False), (2, 4, 50, 50, 128, True),
                                                 (4, 4, 20, 2, 64, False), (3, 4, 20, 197, 128, False), (2, 2, 9, 70, 32, False)])
 def test_attention_backward_one_pass_matches_two_pass(B, H, Tq, Tk, dk, causal, tuning_lib):
     """The LDS-resident backward for short sequences against the general two-pass kernels (both are also pinned by
