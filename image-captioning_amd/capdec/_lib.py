@@ -182,6 +182,7 @@ _TUNING_SIGNATURES = {
     "capdec_lstm_force_staging": (c_int, [c_int]),
     "capdec_attention_bwd_force_two_pass": (c_int, [c_int]),
     "capdec_attention_bwd_force_row_form": (c_int, [c_int]),
+    "capdec_attention_ragged_force_row_form": (c_int, [c_int]),
     "capdec_attention_force_row_kernel": (c_int, [c_int]),
     "capdec_beam_force_unfused": (c_int, [c_int]),
 }

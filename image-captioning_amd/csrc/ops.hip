@@ -469,6 +469,160 @@ __global__ __launch_bounds__(256) void attention_short_kernel(AttnArgs a) {
     }
 }
 
+// Causal self-attention of a ragged training batch at the caption decoder's own shape -- head width 128, at most 32
+// positions -- on the matrix cores: S = Q K^T (32 x 32 x 128 with the sample's rows padded to 32) and O = P V
+// (32 x 128 x 32) as fp32 MFMAs of 16 x 16 x 4 over LDS-resident operands; one workgroup of four wavefronts per
+// (sample, head).  Stage 1: wavefront w owns the 16 x 16 score tile (w >> 1, w & 1); the row maxima and row sums of the
+// two column tiles meet in LDS; stage 2: wavefront w owns the head columns [32w, 32w + 32) of the output, which leaves
+// through LDS as 16-byte stores.  Operand layout: lane (c, g) = (lane & 15, lane >> 4) feeds A[row c][k = 4g' + m] and
+// B[k][column c] of MFMA m; accumulator register e of lane (c, g) is row 4g + e, column c.  Same masks, same
+// log-sum-exp as attention_short_kernel; the sums run in a different order.
+constexpr int AFM_T = 32, AFM_DK = 128, AFM_LD = AFM_DK + 4, AFM_PL = AFM_T + 4;
+static size_t afm_lds_bytes(int rows) {
+    return ((size_t)3 * rows * AFM_LD + AFM_T * AFM_PL + 4 * AFM_T) * sizeof(float);
+}
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int R = a.Tq;                       // rows held per operand (the longest possible sample)
+    float* Qs = lds;
+    float* Ks = Qs + R * AFM_LD;
+    float* Vs = Ks + R * AFM_LD;
+    float* Ps = Vs + R * AFM_LD;              // [32][36] probabilities
+    float* Mx = Ps + AFM_T * AFM_PL;          // [2][32] row maxima per column tile
+    float* Sm = Mx + 2 * AFM_T;               // [2][32] row sums per column tile
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int64_t q0 = a.seq_off[b];
+    const int T = min(a.Tq, a.seq_off[b + 1] - a.seq_off[b]);
+    const int64_t hc = (int64_t)h * AFM_DK;
+    const int ti = wave >> 1, tj = wave & 1;
+    int pad_r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = ti * 16 + 4 * g + e;
+        pad_r[e] = (i < T && a.ids) ? (a.ids[q0 + i] == 0) : 0;
+    }
+    for (int idx = threadIdx.x; idx < R * (AFM_DK / 4); idx += 256) {
+        const int r = idx >> 5, v4 = (idx & 31) * 4;
+        f32x4 xq = {0.f, 0.f, 0.f, 0.f}, xk = xq, xv = xq;
+        if (r < T) {
+            xq = *reinterpret_cast<const f32x4*>(a.q + (q0 + r) * a.ldq + hc + v4);
+            xk = *reinterpret_cast<const f32x4*>(a.k + (q0 + r) * a.ldk + hc + v4);
+            xv = *reinterpret_cast<const f32x4*>(a.v + (q0 + r) * a.ldv + hc + v4);
+        }
+        *reinterpret_cast<f32x4*>(Qs + r * AFM_LD + v4) = xq;
+        *reinterpret_cast<f32x4*>(Ks + r * AFM_LD + v4) = xk;
+        *reinterpret_cast<f32x4*>(Vs + r * AFM_LD + v4) = xv;
+    }
+    __syncthreads();
+    // ---- stage 1: scores, masks, softmax ------------------------------------------------------------------------
+    const float scale = sqrtf((float)AFM_DK);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float* qa = Qs + min(ti * 16 + c, R - 1) * AFM_LD + 4 * g;
+        const float* kb = Ks + min(tj * 16 + c, R - 1) * AFM_LD + 4 * g;
+#pragma unroll
+        for (int kc = 0; kc < AFM_DK / 16; ++kc) {
+            const f32x4 fq = *reinterpret_cast<const f32x4*>(qa + 16 * kc);
+            const f32x4 fk = *reinterpret_cast<const f32x4*>(kb + 16 * kc);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[m], fk[m], acc, 0, 0, 0);
+        }
+    }
+    const int j = tj * 16 + c;
+    bool seen[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = ti * 16 + 4 * g + e;
+        int nkeys = T;
+        if (a.causal && !pad_r[e]) {
+            nkeys = i + a.causal_off + 1;
+            nkeys = nkeys < 1 ? 1 : (nkeys > T ? T : nkeys);
+        }
+        seen[e] = i < T && j < nkeys;
+        acc[e] = acc[e] / scale;
+        float m = (seen[e] && !pad_r[e]) ? acc[e] : -INFINITY;
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        m = fmaxf(m, __shfl_xor(m, 4, 64));
+        m = fmaxf(m, __shfl_xor(m, 8, 64));
+        if (c == 0) Mx[tj * AFM_T + i] = m;
+    }
+    __syncthreads();
+    float mx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = ti * 16 + 4 * g + e;
+        mx[e] = fmaxf(Mx[i], Mx[AFM_T + i]);
+        float pe = 0.f;
+        if (seen[e]) pe = pad_r[e] ? 1.f : expf(acc[e] - mx[e]);     // a <PAD> query row: the same value for every key
+        acc[e] = pe;
+        float sm = pe;
+        sm += __shfl_xor(sm, 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        sm += __shfl_xor(sm, 4, 64);
+        sm += __shfl_xor(sm, 8, 64);
+        if (c == 0) Sm[tj * AFM_T + i] = sm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = ti * 16 + 4 * g + e;
+        const float sum = Sm[i] + Sm[AFM_T + i];
+        Ps[i * AFM_PL + j] = (i < T && acc[e] != 0.f) ? acc[e] / sum : 0.f;
+        if (a.lse && tj == 0 && c == 0 && i < T)
+            a.lse[((int64_t)b * a.H + h) * a.Tq + i] = (pad_r[e] ? -1e9f : mx[e]) + logf(sum);
+    }
+    __syncthreads();
+    // ---- stage 2: O = P V, this wavefront's 32 head columns -------------------------------------------------------
+    f32x4 ao[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) ao[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rt * 16 >= T) break;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            if (kc * 16 >= T) break;
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(Ps + (rt * 16 + c) * AFM_PL + kc * 16 + 4 * g);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int kr = min(kc * 16 + 4 * g + m, R - 1);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    ao[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m], Vs[kr * AFM_LD + wave * 32 + ct * 16 + c],
+                                                                      ao[rt][ct], 0, 0, 0);
+            }
+        }
+    }
+    // the output through LDS (over Q, which nobody reads any more: the last reads were before the barriers above)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = rt * 16 + 4 * g + e;
+                if (r < T) Qs[r * AFM_LD + wave * 32 + ct * 16 + c] = ao[rt][ct][e];
+            }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T * (AFM_DK / 4); idx += 256) {
+        const int r = idx >> 5, v4 = (idx & 31) * 4;
+        *reinterpret_cast<f32x4*>(a.out + (q0 + r) * a.ldo + hc + v4) = *reinterpret_cast<const f32x4*>(Qs + r * AFM_LD + v4);
+    }
+    if (b == a.B - 1) {
+        // the slots between the last sample and the next multiple of 32 belong to no sample but are read by the
+        // contractions that follow: this head's columns of those rows are zeroed here
+        const int live = a.seq_off[a.B], upto = min(a.B * a.Tq, (live + 31) / 32 * 32);
+        for (int idx = threadIdx.x; idx < (upto - live) * (AFM_DK / 4); idx += 256) {
+            const int r = live + idx / (AFM_DK / 4), v4 = (idx % (AFM_DK / 4)) * 4;
+            *reinterpret_cast<f32x4*>(a.out + (int64_t)r * a.ldo + hc + v4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 // Long unmasked memories with several query rows per sample (cross-attention over a token or grid memory: 4 <= Tq <= 64,
 // Tk > 64): one workgroup per (b,h) keeps that head's queries in LDS and streams the keys and values through LDS in
 // chunks of AL_KC rows, each read from memory once; every wavefront carries the running maximum, the running sum and
@@ -949,6 +1103,7 @@ __global__ __launch_bounds__(256) void bn_train_kernel(const float* __restrict__
 }
 
 CAPDEC_HOOK_VAR(g_attention_no_long);   // tests: 1 keeps long memories on the one-wavefront-per-row kernel
+CAPDEC_HOOK_VAR(g_attention_ragged_rows);   // tests: 1 keeps the ragged self-attention on the row-by-row kernel
 
 }  // namespace
 
@@ -1154,6 +1309,16 @@ int capdec_attention_ragged(const float* q, int64_t ldq, const float* k, int64_t
     const size_t short_lds = ((size_t)2 * T * (dk + 16) + 4 * (size_t)T) * sizeof(float);
     CAPDEC_REQUIRE(short_lds <= 64 * 1024);
     AttnArgs a{q, ldq, k, ldk, 0, v, ldv, 0, out, ldo, B, H, T, T, dk, 1, 0, ids, 0, lse, nullptr, 1, nullptr, seq_off};
+    if (dk == AFM_DK && T <= AFM_T && !g_attention_ragged_rows) {
+        // the caption decoder's own shape: scores and context on the matrix cores
+        static const bool ready_m = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)afm_lds_bytes(AFM_T)) == hipSuccess;
+        if (!ready_m) return CAPDEC_EINVAL;
+        hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(B * H)), dim3(256), afm_lds_bytes(T), (hipStream_t)stream, a);
+        CAPDEC_LAUNCH_CHECK();
+        return 0;
+    }
 #define CAPDEC_CALL(NM_) \
     hipLaunchKernelGGL(attention_short_kernel<NM_>, dim3((unsigned)(B * H)), dim3(256), short_lds, (hipStream_t)stream, a)
     CAPDEC_DK_DISPATCH(dk, CAPDEC_CALL);
@@ -1192,6 +1357,10 @@ int capdec_cross_attention_ragged(const float* q, int64_t ldq, const float* k, i
 #ifdef CAPDEC_TUNING_HOOKS
 int capdec_attention_force_row_kernel(int on) {
     g_attention_no_long = on ? 1 : 0;
+    return 0;
+}
+int capdec_attention_ragged_force_row_form(int on) {
+    g_attention_ragged_rows = on ? 1 : 0;
     return 0;
 }
 #endif

@@ -32,6 +32,9 @@ int capdec_attention_bwd_force_row_form(int on);
 /* non-zero: long unmasked memories (more than 64 keys) stay on the one-wavefront-per-row forward kernel instead of the
  * chunked one */
 int capdec_attention_force_row_kernel(int on);
+/* non-zero: the causal self-attention of a ragged batch keeps the row-by-row kernel where the matrix-core form (head
+ * width 128, at most 32 positions) would be taken */
+int capdec_attention_ragged_force_row_form(int on);
 /* non-zero: the KV-cached beam search keeps a step's decoder layers as separate launches (shapes that the one-launch
  * layers of the greedy decoder support normally take those) */
 int capdec_beam_force_unfused(int on);

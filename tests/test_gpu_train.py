@@ -885,9 +885,9 @@ def test_attention_backward_one_pass_matches_two_pass(B, H, Tq, Tk, dk, causal, 
 
 
 @pytest.mark.parametrize("B,T,H", [(1, 1, 1), (9, 20, 4), (33, 32, 2), (64, 7, 4)])
-def test_ragged_self_attention_backward_on_the_matrix_cores(B, T, H, tuning_lib):
-    """Head width 128, at most 32 positions (the caption decoder's own shape): the MFMA form of the ragged self-attention
-    backward against the row-by-row one-pass kernel and against fp64 arithmetic (transformer.py:18-27 differentiated by
+def test_ragged_self_attention_on_the_matrix_cores(B, T, H, tuning_lib):
+    """Head width 128, at most 32 positions (the caption decoder's own shape): the MFMA forms of the ragged self-attention
+    forward and backward against the row-by-row one-pass kernel and against fp64 arithmetic (transformer.py:18-27 differentiated by
     hand: causal rows, <PAD> query rows uniform over the sample's keys), on ragged batches with empty samples."""
     from capdec import ops
     dk = 128
@@ -907,12 +907,21 @@ def test_ragged_self_attention_backward_on_the_matrix_cores(B, T, H, tuning_lib)
     o, lse = ops.attention_ragged(q, k, v, rr, H, want_lse=True)
     got = ops.attention_bwd_ragged(q, k, v, do, lse, rr, H)
     tuning_lib.capdec_attention_bwd_force_row_form(1)
+    tuning_lib.capdec_attention_ragged_force_row_form(1)
     try:
+        o_rows, lse_rows = ops.attention_ragged(q, k, v, rr, H, want_lse=True)
         rows = ops.attention_bwd_ragged(q, k, v, do, lse, rr, H)
     finally:
         tuning_lib.capdec_attention_bwd_force_row_form(0)
+        tuning_lib.capdec_attention_ragged_force_row_form(0)
     live = int(rr.counts[1])
     up = int(rr.counts[0])
+    # forward: output rows (zero between the last sample and the row limit) and the log-sum-exp of the live rows
+    close(o[:up], o_rows[:up].cpu().numpy(), rtol=2e-6, what="forward output vs the row form")
+    assert up == live or float(o[live:up].abs().max()) == 0.0
+    lens = (rr.seq_off[1:] - rr.seq_off[:-1]).cpu()
+    live_mask = (torch.arange(T)[None, None, :] < lens[:, None, None]).expand(B, H, T)
+    close(lse.cpu()[live_mask], lse_rows.cpu()[live_mask].numpy(), rtol=2e-6, what="log-sum-exp vs the row form")
     for a_, b_, name in zip(got, rows, ("dq", "dk", "dv")):
         close(a_[:up], b_[:up].cpu().numpy(), rtol=2e-6, what=name + " vs the row form")
         assert float(a_[live:up].abs().max()) == 0.0 if up > live else True
@@ -920,6 +929,7 @@ def test_ragged_self_attention_backward_on_the_matrix_cores(B, T, H, tuning_lib)
     off = rr.seq_off.cpu().tolist()
     idc = rr.ids_c.cpu()
     want = [torch.zeros(M, E, dtype=torch.float64) for _ in range(3)]
+    want_o = torch.zeros(M, E, dtype=torch.float64)
     q64, k64, v64, do64 = (x.double().cpu() for x in (q, k, v, do))
     for b in range(B):
         s0, s1 = off[b], off[b + 1]
@@ -938,8 +948,10 @@ def test_ragged_self_attention_backward_on_the_matrix_cores(B, T, H, tuning_lib)
             out = torch.softmax(sc, dim=-1) @ vv
             out.backward(do64[s0:s1, cs])
             want[0][s0:s1, cs], want[1][s0:s1, cs], want[2][s0:s1, cs] = qq.grad, kk.grad, vv.grad
+            want_o[s0:s1, cs] = out.detach()
     for a_, w_, name in zip(got, want, ("dq", "dk", "dv")):
         close(a_[:live], w_[:live].numpy(), rtol=1e-5, what=name + " vs fp64")
+    close(o[:live], want_o[:live].numpy(), rtol=1e-5, what="forward output vs fp64")
 
 
 def test_checkpoint_roundtrip_resumes_training_exactly(tmp_path):

@@ -92,7 +92,7 @@ def main():
     # the forms the trainer takes: the same batch as a ragged one (every row live here)
     ids64 = ids32.to(torch.int64)
     rr = ops.RaggedRows(ids64, ids64, 0)
-    hbm("attention_short_kernel (ragged batch: the trainer's forward)", "B=512,H=4,T=20", 4.0 * Mt * E * 4,
+    hbm("attention_mfma_kernel (ragged batch: the trainer's forward, matrix cores)", "B=512,H=4,T=20", 4.0 * Mt * E * 4,
         lambda: ops.attention_ragged(q, k, v, rr, H, want_lse=True))
     _, lse_r = ops.attention_ragged(q, k, v, rr, H, want_lse=True)
     hbm("attn_bwd_mfma_kernel (ragged batch: the trainer's backward, matrix cores)", "B=512,H=4,T=20", 7.0 * Mt * E * 4,
