@@ -87,7 +87,7 @@ def main():
     hbm("attention_kernel (train, causal)", "B=512,H=4,T=20", 4.0 * Mt * E * 4,
         lambda: ops.attention(q, k, v, Bt, H, Tt, Tt, causal=True, ids32=ids32, want_lse=True))
     o, lse = ops.attention(q, k, v, Bt, H, Tt, Tt, causal=True, ids32=ids32, want_lse=True)
-    hbm("attn_bwd_fused_kernel", "B=512,H=4,T=20", 7.0 * Mt * E * 4,
+    hbm("attn_bwd_mfma_kernel (dense call: the matrix-core form at this shape)", "B=512,H=4,T=20", 7.0 * Mt * E * 4,
         lambda: ops.attention_bwd(q, k, v, dy, lse, Bt, H, Tt, Tt, causal=True, ids32=ids32))
     # the forms the trainer takes: the same batch as a ragged one (every row live here)
     ids64 = ids32.to(torch.int64)
