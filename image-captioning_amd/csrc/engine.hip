@@ -280,11 +280,25 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
         }
     };
     if (VEC) {
+        // eight 16-byte loads of a lane in flight at a time (one memory round trip per 8 KiB of the row, not per 1 KiB:
+        // the row is a dependent chain otherwise, 40 us whatever the batch); the values are taken in the same order
         const f32x4* l4 = reinterpret_cast<const f32x4*>(lr);
-        for (int c = lane; c < V / 4; c += 64) {
-            const f32x4 v = l4[c];
+        const int n4 = V / 4;
+        for (int c0 = lane; c0 < n4; c0 += 64 * 8) {
+            f32x4 v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) take(v[e], 4 * c + e);
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + 64 * u;
+                v[u] = l4[c < n4 ? c : n4 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + 64 * u;
+                if (c < n4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) take(v[u][e], 4 * c + e);
+                }
+            }
         }
     } else {
         for (int c = lane; c < V; c += 64) take(lr[c], c);
@@ -301,6 +315,97 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
             for (int q = 0; q + 1 < CAP; ++q) { bv[q] = bv[q + 1]; bi[q] = bi[q + 1]; }
             bv[CAP - 1] = -INFINITY; bi[CAP - 1] = INT_MAX;
         }
+        if (lane == 0) {
+            top_lp[(int64_t)row * W + k] = v - lse;
+            top_id[(int64_t)row * W + k] = (i >= 0 && i < V) ? i : 0;
+        }
+    }
+}
+
+// The same with a whole workgroup per row, for batches too small to fill the chip with one wavefront per row (a
+// wavefront walks its row alone: 156 values per lane at V = 10000, about 30 us whatever the batch): the four
+// wavefronts sweep contiguous quarters of the row, their (max, sum exp) pairs and W best candidates meet in LDS and
+// the first wavefront merges them -- the sums in quarter order, the candidates by (value, lowest id).
+template <int CAP, bool VEC>
+__global__ __launch_bounds__(256) void beam_topk_row_kernel(const float* __restrict__ logits, int64_t ld, int N, int V, int W,
+                                                            float* __restrict__ top_lp, int32_t* __restrict__ top_id) {
+    __shared__ float s_mx[4], s_sm[4], s_v[4 * BEAM_MAX_W];
+    __shared__ int s_i[4 * BEAM_MAX_W];
+    const int row = blockIdx.x, part = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* lr = logits + (int64_t)row * ld;
+    float bv[CAP];
+    int bi[CAP];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) { bv[k] = -INFINITY; bi[k] = INT_MAX; }
+    float mx = -INFINITY, sm = 0.f;
+    auto take = [&](float v, int c) {
+        if (v > mx) { sm *= __expf(mx - v); mx = v; }
+        sm += __expf(v - mx);
+        if (!(v > bv[CAP - 1])) return;
+        float cv = v;
+        int ci = c;
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) {
+            if (cv > bv[k]) {
+                const float tv = bv[k]; const int ti = bi[k];
+                bv[k] = cv; bi[k] = ci;
+                cv = tv; ci = ti;
+            }
+        }
+    };
+    if (VEC) {
+        const f32x4* l4 = reinterpret_cast<const f32x4*>(lr);
+        const int n4 = V / 4, lo = (int)((int64_t)n4 * part / 4), hi = (int)((int64_t)n4 * (part + 1) / 4);
+        for (int c0 = lo + lane; c0 < hi; c0 += 64 * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + 64 * u;
+                v[u] = l4[c < hi ? c : hi - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + 64 * u;
+                if (c < hi) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) take(v[u][e], 4 * c + e);
+                }
+            }
+        }
+    } else {
+        const int lo = (int)((int64_t)V * part / 4), hi = (int)((int64_t)V * (part + 1) / 4);
+        for (int c = lo + lane; c < hi; c += 64) take(lr[c], c);
+    }
+    const float wm = wave_max(mx);
+    sm = wave_sum(mx > -INFINITY ? sm * __expf(mx - wm) : 0.f);
+    if (lane == 0) { s_mx[part] = wm; s_sm[part] = sm; }
+    for (int k = 0; k < W; ++k) {
+        float v = bv[0];
+        int i = bi[0];
+        wave_argmax(v, i);
+        if (bi[0] == i) {
+#pragma unroll
+            for (int q = 0; q + 1 < CAP; ++q) { bv[q] = bv[q + 1]; bi[q] = bi[q + 1]; }
+            bv[CAP - 1] = -INFINITY; bi[CAP - 1] = INT_MAX;
+        }
+        if (lane == 0) { s_v[part * BEAM_MAX_W + k] = v; s_i[part * BEAM_MAX_W + k] = i; }
+    }
+    __syncthreads();
+    if (part != 0) return;
+    float M = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+    float S = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S += s_mx[q] > -INFINITY ? s_sm[q] * __expf(s_mx[q] - M) : 0.f;
+    const float lse = M + logf(S);
+    // lane q*W + k holds candidate k of quarter q; W rounds of "best remaining"
+    float cv = -INFINITY;
+    int ci = INT_MAX;
+    if (lane < 4 * W) { cv = s_v[(lane / W) * BEAM_MAX_W + lane % W]; ci = s_i[(lane / W) * BEAM_MAX_W + lane % W]; }
+    for (int k = 0; k < W; ++k) {
+        float v = cv;
+        int i = ci;
+        wave_argmax(v, i);
+        if (ci == i) { cv = -INFINITY; ci = INT_MAX; }      // (ids are distinct: exactly one lane holds the winner)
         if (lane == 0) {
             top_lp[(int64_t)row * W + k] = v - lse;
             top_id[(int64_t)row * W + k] = (i >= 0 && i < V) ? i : 0;
@@ -1356,9 +1461,15 @@ static int beam_pick(const BeamBufs& d, int t, int B, int W, int V, int eos, int
                      int32_t* pad_seen = nullptr) {
     const int N = B * W;
     const bool vec = V % 4 == 0 && capdec_aligned16(d.logits);
+    // up to 1024 hypothesis rows: a workgroup per row (one wavefront per row leaves most of the chip idle there)
+    const bool by_row = N <= 1024 && V >= 1024;
 #define CAPDEC_TOPK(CAP_)                                                                                               \
     do {                                                                                                                \
-        if (vec) hipLaunchKernelGGL((beam_topk_kernel<CAP_, true>), dim3((N + 3) / 4), dim3(256), 0, s, d.logits,       \
+        if (by_row && vec) hipLaunchKernelGGL((beam_topk_row_kernel<CAP_, true>), dim3(N), dim3(256), 0, s, d.logits,   \
+                                              (int64_t)V, N, V, W, d.top_lp, d.top_id);                                 \
+        else if (by_row) hipLaunchKernelGGL((beam_topk_row_kernel<CAP_, false>), dim3(N), dim3(256), 0, s, d.logits,    \
+                                            (int64_t)V, N, V, W, d.top_lp, d.top_id);                                   \
+        else if (vec) hipLaunchKernelGGL((beam_topk_kernel<CAP_, true>), dim3((N + 3) / 4), dim3(256), 0, s, d.logits,  \
                                     (int64_t)V, N, V, W, d.top_lp, d.top_id);                                           \
         else hipLaunchKernelGGL((beam_topk_kernel<CAP_, false>), dim3((N + 3) / 4), dim3(256), 0, s, d.logits,          \
                                 (int64_t)V, N, V, W, d.top_lp, d.top_id);                                               \
