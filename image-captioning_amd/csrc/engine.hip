@@ -437,9 +437,14 @@ __global__ void beam_init_kernel(BeamState st, int64_t ldtok, int N, int sos, in
 // median of three moved to the front, unguarded Hoare partition, insertion sort below four elements, heap select once
 // the depth limit 2 * floor(log2 n) is used up -- followed by one insertion sort (fewer than 16 elements).  The
 // functions below perform the same element moves, so the result is the same permutation, ties included.
+// A thread's row lives in LDS, element a at [a][thread] (the algorithm indexes its row with run-time indices: as a
+// private array it would sit in scratch memory, a memory round trip per access).  Workgroups of TOPK_THREADS threads.
+constexpr int TOPK_THREADS = 64, TOPK_MAX_N = BEAM_MAX_W * BEAM_MAX_W;
+struct TopkVals { float* p; __device__ float& operator[](int a) const { return p[a * TOPK_THREADS]; } };
+struct TopkIdxs { int* p; __device__ int& operator[](int a) const { return p[a * TOPK_THREADS]; } };
 struct TopkRow {
-    float v[BEAM_MAX_W * BEAM_MAX_W];
-    int i[BEAM_MAX_W * BEAM_MAX_W];
+    TopkVals v;
+    TopkIdxs i;
     __device__ void swap(int a, int b) {
         const float tv = v[a]; v[a] = v[b]; v[b] = tv;
         const int ti = i[a]; i[a] = i[b]; i[b] = ti;
@@ -542,9 +547,11 @@ __device__ inline void topk_cpu_order(TopkRow& q, int n, int k) {
 
 __global__ void topk_rows_kernel(const float* __restrict__ x, int rows, int n, int k, float* __restrict__ out_val,
                                  int32_t* __restrict__ out_idx) {
+    __shared__ float sv[TOPK_MAX_N * TOPK_THREADS];
+    __shared__ int si[TOPK_MAX_N * TOPK_THREADS];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    TopkRow q;
+    TopkRow q{{sv + threadIdx.x}, {si + threadIdx.x}};
     for (int c = 0; c < n; ++c) { q.v[c] = x[(int64_t)r * n + c]; q.i[c] = c; }
     topk_cpu_order(q, n, k);
     for (int c = 0; c < k; ++c) { out_val[(int64_t)r * k + c] = q.v[c]; out_idx[(int64_t)r * k + c] = q.i[c]; }
@@ -565,12 +572,28 @@ __global__ void beam_select_kernel(int step, int B, int W, int eos, BeamState cu
                                    const float* __restrict__ top_lp, const int32_t* __restrict__ top_id,
                                    int32_t* __restrict__ parent, int32_t* __restrict__ unfinished,
                                    int32_t* __restrict__ pad_seen = nullptr) {
+    __shared__ float sv[TOPK_MAX_N * TOPK_THREADS];
+    __shared__ int si[TOPK_MAX_N * TOPK_THREADS];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    // a hypothesis' token prefix, eight loads in flight at a time (the two states never alias; a load-store chain per
+    // token made this kernel grow from 10 to 30 us over 20 steps)
+    auto copy_prefix = [&](int dst, int src) {
+        const int32_t* sp = cur.tok + (int64_t)src * ldtok;
+        int32_t* dp = nxt.tok + (int64_t)dst * ldtok;
+        for (int p0 = 0; p0 <= step; p0 += 8) {
+            int32_t tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tmp[u] = sp[min(p0 + u, step)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + u <= step) dp[p0 + u] = tmp[u];
+        }
+    };
     if (step > 0 && unfinished[step - 1] == 0) {           // the reference's loop has ended: keep everything
         for (int w = 0; w < W; ++w) {
             const int n = b * W + w;
-            for (int p = 0; p <= step; ++p) nxt.tok[(int64_t)n * ldtok + p] = cur.tok[(int64_t)n * ldtok + p];
+            copy_prefix(n, n);
             nxt.tok[(int64_t)n * ldtok + step + 1] = eos;
             nxt.score[n] = cur.score[n];
             nxt.done[n] = 1;
@@ -578,7 +601,7 @@ __global__ void beam_select_kernel(int step, int B, int W, int eos, BeamState cu
         }
         return;                                            // unfinished[step] stays 0
     }
-    TopkRow q;
+    TopkRow q{{sv + threadIdx.x}, {si + threadIdx.x}};
     for (int w = 0; w < W; ++w) {
         const int n = b * W + w;
         const float keep = cur.done[n] != 0 ? 0.f : 1.f;
@@ -596,7 +619,7 @@ __global__ void beam_select_kernel(int step, int B, int W, int eos, BeamState cu
         const int pw = best / W, pk = best - pw * W;
         const int src = b * W + pw, dst = b * W + r;
         const int tokn = top_id[(int64_t)src * W + pk];
-        for (int p = 0; p <= step; ++p) nxt.tok[(int64_t)dst * ldtok + p] = cur.tok[(int64_t)src * ldtok + p];
+        copy_prefix(dst, src);
         nxt.tok[(int64_t)dst * ldtok + step + 1] = tokn;
         nxt.score[dst] = q.v[r];
         const int fin = tokn == eos ? 1 : 0;
