@@ -638,13 +638,58 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     for (int c = threadIdx.x; c < EB_HOT * E; c += 256) lds[c] = 0.f;
     if (threadIdx.x < EB_HOT) used[threadIdx.x] = 0;
     __syncthreads();
-    for (int rr = wave; rr < EB_ROWS; rr += 4) {
+    // the ids of this wavefront's rows up front (lane k holds the id of its k-th row; EB_ROWS <= 64: at most 16), and the
+    // next row's values in flight while the current row's atomics are issued: otherwise a row is a chain of an id load,
+    // a row load and the atomics, about 4 us
+    int my_id = 0;
+    {
+        const int row = blockIdx.x * EB_ROWS + wave + 4 * lane;
+        if (wave + 4 * lane < EB_ROWS && row < rows) {
+            const long raw = ids[row];
+            my_id = (int)(raw < 0 ? 0 : (raw >= V ? V - 1 : raw));
+        }
+    }
+    constexpr int EB_PF = 8;                       // prefetched floats per lane: rows of up to 512 floats
+    const bool pf = E <= 64 * EB_PF;
+    float nxt[EB_PF];
+    auto fetch = [&](int row) {
+#pragma unroll
+        for (int j = 0; j < EB_PF; ++j) {
+            const int c = lane + 64 * j;
+            nxt[j] = (row < rows && c < E) ? dx[(int64_t)row * E + c] : 0.f;
+        }
+    };
+    if (pf) fetch(blockIdx.x * EB_ROWS + wave);
+    int k = 0;
+    for (int rr = wave; rr < EB_ROWS; rr += 4, ++k) {
         const int row = blockIdx.x * EB_ROWS + rr;
         if (row >= rows) break;
-        long id = ids[row];
-        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        const long id = __shfl(my_id, k, 64);
         const float* src = dx + (int64_t)row * E;
         const uint64_t e0 = (uint64_t)row * E;
+        if (pf) {
+            float cur[EB_PF];
+#pragma unroll
+            for (int j = 0; j < EB_PF; ++j) cur[j] = nxt[j];
+            if (rr + 4 < EB_ROWS) fetch(row + 4);
+#pragma unroll
+            for (int j = 0; j < EB_PF; ++j) {
+                const int c = lane + 64 * j;
+                cur[j] = p > 0.f ? cur[j] * drop_scale(seed, e0 + c, p, inv_keep) : cur[j];
+            }
+            if (id < EB_HOT) {
+                if (lane == 0) used[id] = 1;
+#pragma unroll
+                for (int j = 0; j < EB_PF; ++j)
+                    if (lane + 64 * j < E) atomicAdd(&lds[id * E + lane + 64 * j], cur[j]);
+            } else {
+                float* dst = demb + id * (int64_t)E;
+#pragma unroll
+                for (int j = 0; j < EB_PF; ++j)
+                    if (lane + 64 * j < E) atomicAdd(&dst[lane + 64 * j], cur[j]);
+            }
+            continue;
+        }
         if (id < EB_HOT) {
             if (lane == 0) used[id] = 1;
             for (int c = lane; c < E; c += 64)
