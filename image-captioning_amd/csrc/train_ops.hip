@@ -562,8 +562,16 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict_
     const int64_t r0 = seg_off ? seg_off[g] : (int64_t)g * T;
     if (seg_off) T = seg_off[g + 1] - seg_off[g];
     for (int c = lane; c < nv; c += 64) {
+        // eight rows in flight at a time, added in row order (one row per round trip made 20 rows 25 us)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < T; ++t) acc += reinterpret_cast<const f32x4*>(x + (r0 + t) * E)[c];
+        for (int t0 = 0; t0 < T; t0 += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const f32x4*>(x + (r0 + min(t0 + u, T - 1)) * E)[c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t0 + u < T) acc += v[u];
+        }
         reinterpret_cast<f32x4*>(out + (int64_t)g * E)[c] = acc;
     }
 }
