@@ -421,13 +421,19 @@ __global__ __launch_bounds__(256) void pair_gate_bwd_kernel(const float* __restr
 #pragma unroll
         for (int u = 0; u < NV; ++u) ac[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int row = r0 + wave; row < r1; row += 4) {
+            // everything a row needs in flight together: its x1 and d_a2 values, the four gates, and the d_x1 values the
+            // result is added to (loaded where they are used, each gate and the read-modify-write were a round trip of
+            // their own: five per row)
             f32x4 x[NV], da[NV], dx[NV];
+            float pg4[4];
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) pg4[hh] = h0 + hh < H ? p_in[(int64_t)row * H + h0 + hh] : 0.f;
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int c = lane + 64 * u;
                 x[u] = c < nv ? reinterpret_cast<const f32x4*>(x1 + (int64_t)row * E)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
                 da[u] = c < nv ? reinterpret_cast<const f32x4*>(d_a2 + (int64_t)row * E)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-                dx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dx[u] = c < nv ? reinterpret_cast<const f32x4*>(d_x1 + (int64_t)row * E)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
                 if (h0 == 0) ac[u] += da[u];
             }
 #pragma unroll
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(256) void pair_gate_bwd_kernel(const float* __restr
 #pragma unroll
                 for (int u = 0; u < NV; ++u)
                     part += da[u][0] * d[hh][u][0] + da[u][1] * d[hh][u][1] + da[u][2] * d[hh][u][2] + da[u][3] * d[hh][u][3];
-                const float p = p_in[(int64_t)row * H + h0 + hh];
+                const float p = pg4[hh];
                 const float dz = wave_sum(part) * p * (1.0f - p) * scale;
                 as[hh] += dz;
 #pragma unroll
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(256) void pair_gate_bwd_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int c = lane + 64 * u;
-                if (c < nv) reinterpret_cast<f32x4*>(d_x1 + (int64_t)row * E)[c] += dx[u];
+                if (c < nv) reinterpret_cast<f32x4*>(d_x1 + (int64_t)row * E)[c] = dx[u];
             }
         }
         // partial sums of the four wavefronts -> LDS, one wavefront at a time
