@@ -109,6 +109,22 @@ def test_beam_medium_size_against_oracle():
         assert _rows(ids, lengths) == want
 
 
+@pytest.mark.parametrize("W", [2, 5, 8])
+def test_beam_widths_of_every_top_w_list_size_against_oracle(W):
+    """The log-softmax / top-W sweep keeps per-lane lists of 2, 4 or 8 candidates depending on the width, and takes a
+    workgroup per hypothesis row at these sizes: widths 2, 5 and 8 at V = 2000 against the oracle (hypotheses, scores)."""
+    from gpu_util import cpu_sd, plain_decoder
+    torch.manual_seed(10 + W)
+    dec = plain_decoder(512, 2000, 4, 2).cuda().eval()
+    sd = cpu_sd(dec)
+    g = torch.Generator().manual_seed(90 + W)
+    enc = torch.randn(5, 1, 512, generator=g)
+    want, _, want_scores = R.beam_search_ids(sd, enc, 4, W, 7, return_state=True)
+    ids, lengths, scores = dec.beam_ids(enc.cuda(), R.SOS, R.EOS, W, 7, return_scores=True)
+    close(scores, want_scores, rtol=1e-4, atol=1e-4, what="scores")
+    assert _rows(ids, lengths) == want
+
+
 def test_cached_beam_equals_full_prefix_beam_at_batch_256():
     """Rows are independent and the two forms compute the same function: identical best hypotheses (up to a
     near-tie) and scores on a larger batch with one and with 64 memory rows."""
