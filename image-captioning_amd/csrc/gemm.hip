@@ -1138,6 +1138,10 @@ int launch_gemm_layout(GemmKArgs& a, int ngroups, int maxI, int maxJ, bool vec, 
         //  input gradient 44.6 us on 64x64 tiles at BK 16 against 45.5 at BK 32; at 10240 rows the 64x64 tiles stay:
         //  tools/exp/tile_probe.py.  Giving a wavefront 64x32 instead of 32x32 does not lift the 53-56 % of the MFMA peak
         //  these 512-deep launches reach: their LDS reads are not what holds them.)
+        // (the training logits, 7488 ... 10240 x 10000 x 512, some 18000 tiles: launched back to back on their own, BK 32
+        //  takes 675 / 903 us against 693-715 / 918-924 at BK 16, 128x64 tiles 700 / 925, 128x128 ones 742-760 / 979-998
+        //  (tools/exp/vocab_tile_probe.py); inside the training step the two k-tile depths give the same 5.44-5.46 ms,
+        //  so the rule stays as it is)
         else cfg = tiles64 <= 160 ? 32 : (tiles64 < 512 ? 316 : (tiles64 < 1024 ? (TQ ? 116 : 2132) : 116));
     }
     if (cfg == 2116) return launch_gemm_cfg<2, 2, 1, 16, TP, TQ, 1>(a, ngroups, maxI, maxJ, vec, s);
