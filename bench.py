@@ -758,7 +758,8 @@ def main():
     for i in range(args.steps):
         _, _, nd = step(probes[i] if i < len(probes) else None)
         dirty_rows += nd
-        torch.cuda.synchronize()          # ids are already on the host here; this only covers rank != 0
+        if DIST_ON:
+            torch.cuda.synchronize()      # one GPU: the ids are already on the host here (the decode call waited for its copy)
     fence()
     dt = time.perf_counter() - t0
     for pr in probes:

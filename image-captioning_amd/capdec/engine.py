@@ -153,11 +153,11 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
                     # the one host sync of the decode
                     if to_cpu:
                         host = to_host()
-                        rows = torch.nonzero(host[2], as_tuple=False).flatten()
                     else:
-                        rows = torch.nonzero(dirty.cpu(), as_tuple=False).flatten()
                         host = (None, None, dirty.cpu())
-                    n_dirty = int(rows.numel())
+                    # (almost always no flag is set: one reduction instead of building an index list)
+                    rows = torch.nonzero(host[2], as_tuple=False).flatten() if bool(host[2].any()) else None
+                    n_dirty = 0 if rows is None else int(rows.numel())
                     if n_dirty and bool((host[2] == 2).any()):
                         warnings.warn("capdec: a workgroup of the one-launch decoder layers gave up waiting for its team; "
                                       "the batch is re-decoded on the exact path", RuntimeWarning)

@@ -30,15 +30,12 @@ def linear_dropout_bn(model, parts, x, dropout_first=False):
     E = parts[0][0].weight.shape[0]
     # a long contraction with few output tiles (the 86436-wide YOLO projection) is split over workgroups, its partial
     # sums added in a fixed order: the memory rows, and with them the decoded tokens, repeat exactly from run to run
-    out = torch.empty((B, len(parts) * E), device=x.device, dtype=torch.float32)
-    scale, shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
     # (likewise a small batch in front of a 1000- or 2048-wide feature: at batch 32 the CNN head is four 64x64 tiles
     #  that each walk all 2048 k, 26.7 us on four of the chip's 256 compute units)
     few_tiles = ((B + 63) // 64) * ((E + 63) // 64) <= 32
-    for n, (fc, lo, hi) in enumerate(parts):
-        ops.linear(x[:, lo:hi], fc.weight, fc.bias, scale=scale[n * E:(n + 1) * E], shift=shift[n * E:(n + 1) * E],
-                   out=out[:, n * E:(n + 1) * E], split_k=(hi - lo >= 8192) or (few_tiles and hi - lo >= 1024))
-    return out
+    return ops.head_eval(x, [(fc.weight, fc.bias, lo, hi) for fc, lo, hi in parts], bn.weight, bn.bias,
+                         bn.running_mean, bn.running_var, bn.eps,
+                         lambda K: K >= 8192 or (few_tiles and K >= 1024))
 
 
 def decoder_forward(dec, enc_output, captions, take_last=False):

@@ -185,6 +185,48 @@ def bn_fold(gamma, beta, running_mean, running_var, eps=1e-5):
     return scale, shift
 
 
+def head_eval(x, parts, gamma, beta, running_mean, running_var, eps, split_k):
+    """Eval-mode feature head: ``capdec_bn_fold`` of the BatchNorm's running statistics, then for each ``(W [E,hi-lo], b [E], lo, hi)`` of ``parts`` the contraction of ``x[:, lo:hi]`` with W
+    whose epilogue applies that part's scale and shift, written into its E columns of the [B, len(parts)*E] result.
+    The operands go to the library as addresses and strides (no tensor views on the way: the head is on the host's
+    critical path of every synchronous decode call).  ``split_k(K)`` says whether a part takes the fixed-order split
+    of a long contraction (``linear(..., split_k=True)``)."""
+    lib = _lib.load()
+    _chk(x, name="x")
+    B, F = x.shape
+    ldx = _row_stride(x, "x")
+    E = parts[0][0].shape[0]
+    C = len(parts) * E
+    for t, nm in ((gamma, "batchnorm.weight"), (beta, "batchnorm.bias"), (running_mean, "batchnorm.running_mean"),
+                  (running_var, "batchnorm.running_var")):
+        if _chk(t, name=nm).numel() != C or not t.is_contiguous():
+            raise RuntimeError(f"capdec head: {nm} must hold {C} contiguous values")
+    out = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    fold = torch.empty((2 * C,), device=x.device, dtype=torch.float32)         # scale, then shift
+    fp, xp, op, s = fold.data_ptr(), x.data_ptr(), out.data_ptr(), _stream()
+    _lib.check(lib.capdec_bn_fold(gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                                  eps, C, fp, fp + 4 * C, s), "capdec_bn_fold")
+    arr = (GemmGroup * 1)()
+    g = arr[0]
+    for n, (W, b, lo, hi) in enumerate(parts):
+        K = hi - lo
+        _chk(W, name="fc.weight")
+        if b is not None and (_chk(b, name="fc.bias").numel() != E or not b.is_contiguous()):
+            raise RuntimeError(f"capdec head: part {n}: bias {tuple(b.shape)} for {E} outputs")
+        if not 0 <= lo < hi <= F or tuple(W.shape) != (E, K) or not W.is_contiguous():
+            raise RuntimeError(f"capdec head: part {n} does not fit: x {tuple(x.shape)}, columns {lo}:{hi}, "
+                               f"weight {tuple(W.shape)}")
+        if split_k(K):
+            linear(x[:, lo:hi], W, b, scale=fold[n * E:(n + 1) * E], shift=fold[C + n * E:C + (n + 1) * E],
+                   out=out[:, n * E:(n + 1) * E], split_k=True)
+            continue
+        g.P, g.Q, g.C = xp + 4 * lo, W.data_ptr(), op + 4 * n * E
+        g.ldp, g.ldq, g.ldci, g.ldcj, g.I, g.J = ldx, K, C, 1, B, E
+        g.bias_j, g.scale_j, g.shift_j = _ptr(b), fp + 4 * n * E, fp + 4 * (C + n * E)
+        _lib.check(lib.capdec_gemm(arr, 1, K, 0, s), "capdec_gemm")
+    return out
+
+
 def bn_train_forward(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
     lib = _lib.load()
     _chk(x, name="x")

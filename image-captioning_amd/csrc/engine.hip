@@ -949,9 +949,26 @@ static size_t carve_decode(const capdec_tf_model* m, int B, int S, int max_len, 
 
 __global__ void cached_init_kernel(int32_t* tok, int64_t ldtok, int32_t* done, int32_t* first_pad, int64_t* out_ids,
                                    int32_t* out_len, int32_t* dirty, int32_t* rowmap, int32_t* nrows,
-                                   int32_t* fin, int B, int max_len, int sos, int32_t* pcount, int32_t* plist, int nteams) {
+                                   int32_t* fin, int B, int max_len, int sos, int32_t* pcount, int32_t* plist, int nteams,
+                                   const float* __restrict__ emb, const float* __restrict__ pe, int E, float* __restrict__ x,
+                                   unsigned* ctr, int ctr_n) {
     const int n = B * max_len;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    // step 0's input rows: every caption starts at <SOS>, position 0 (the sum embed_pe_kernel would form, row by row)
+    {
+        const int e4 = E / 4;
+        const f32x4* src = reinterpret_cast<const f32x4*>(emb + (int64_t)sos * E);
+        const f32x4* pp = reinterpret_cast<const f32x4*>(pe);
+        f32x4* dst = reinterpret_cast<f32x4*>(x);
+        for (int idx = tid; idx < B * e4; idx += nth) {
+            const int c = idx % e4;
+            f32x4 v = src[c];
+            v += pp[c];
+            dst[idx] = v;
+        }
+    }
+    // arrival counters of the one-launch layers (every step's start at zero) and their error word
+    for (int idx = tid; idx < ctr_n; idx += nth) ctr[idx] = 0;
     for (int idx = tid; idx < n; idx += nth) out_ids[idx] = -1;
     for (int b = tid; b < B; b += nth) {
         tok[(int64_t)b * ldtok] = sos;
@@ -1131,15 +1148,18 @@ int capdec_tf_greedy_decode(const capdec_tf_model* m, const float* enc, int B, i
                                 (S >= CAPDEC_DECODE_FOLD_MIN_ROWS && !(flags & CAPDEC_DECODE_NO_S1_SHORTCUT)));
     CAPDEC_REQUIRE(!(flags & CAPDEC_DECODE_FOLD_MEMORY) || fold);      // forced but unavailable (S < 3 or E not built)
 
-    hipLaunchKernelGGL(cached_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, w.first_pad, out_ids,
-                       out_len, out_dirty, w.rowmap, w.nrows, w.fin, B, max_len, sos, w.pcount, w.plist, w.fused_teams);
-    CAPDEC_LAUNCH_CHECK();
-    CAPDEC_TRY(capdec_embed_pe(w.tok, 1, ldtok, m->emb, m->pe, 0, B, 1, E, V, w.x, stream));
     // all layers of a step in one launch (one or two memory rows, supported shape): the arrival counters of every step start at zero
     const bool fused = (s1 || s2) && w.ctr && !(flags & CAPDEC_DECODE_NO_FUSED_LAYERS);
     const size_t ctr_step = (size_t)w.fused_teams * 32;
     unsigned* fuse_err = fused ? w.ctr + (size_t)max_len * ctr_step : nullptr;
-    if (fused) CAPDEC_TRY((int)hipMemsetAsync(w.ctr, 0, ((size_t)max_len * ctr_step + 32) * sizeof(unsigned), s));
+    const size_t ctr_n = fused ? (size_t)max_len * ctr_step + 32 : 0;
+    CAPDEC_REQUIRE(ctr_n < INT_MAX && (int64_t)B * (E / 4) < INT_MAX);
+    if (!capdec_aligned16(m->emb) || !capdec_aligned16(m->pe)) return CAPDEC_EALIGN;        // rows are read 16 bytes at a time
+    // one launch: the bookkeeping arrays, step 0's embedded rows (<SOS> at position 0) and the counters
+    hipLaunchKernelGGL(cached_init_kernel, dim3(256), dim3(256), 0, s, w.tok, ldtok, w.done, w.first_pad, out_ids,
+                       out_len, out_dirty, w.rowmap, w.nrows, w.fin, B, max_len, sos, w.pcount, w.plist, w.fused_teams,
+                       m->emb, m->pe, E, w.x, fused ? w.ctr : nullptr, (int)ctr_n);
+    CAPDEC_LAUNCH_CHECK();
 
     if (s1) {
         // softmax over one key is exactly 1, so the block's output is W_o(W_v enc + b_v) + b_o for every
