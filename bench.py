@@ -726,20 +726,21 @@ def main():
         with torch.no_grad():
             enc = model.encode_features(feats).view(B, S, E)
             # one GPU: ids, lengths and flags come to the host in one copy; several: they stay on the device for the gather
-            ids, lens, n_dirty = engine.tf_greedy_ids(ref, enc, LEN, 1, 2, probe=probe, to_cpu=not DIST_ON)
+            kept = [] if DIST_ON else None
+            ids, lens, n_dirty = engine.tf_greedy_ids(ref, enc, LEN, 1, 2, probe=probe, to_cpu=not DIST_ON, keep_pack=kept)
             if DIST_ON:
-                # batch-sharded decode: the only exchange is the final gather of the token ids
+                # batch-sharded decode: the only exchange is the final gather, and the rank's ids, lengths and flags lie
+                # back to back in one allocation, so one collective (and on rank 0 one copy to the host) moves them all
+                pack = kept[0]
                 if rehearsal:                       # gloo gathers host tensors only
-                    ids, lens = ids.cpu(), lens.cpu()
-                gdev = ids.device
-                all_ids = torch.empty((world * B, LEN), dtype=torch.int64, device=gdev) if rank == 0 else None
-                all_len = torch.empty((world * B,), dtype=torch.int32, device=gdev) if rank == 0 else None
-                dist.gather(ids, list(all_ids.chunk(world)) if rank == 0 else None, dst=0)
-                dist.gather(lens, list(all_len.chunk(world)) if rank == 0 else None, dst=0)
+                    pack = pack.cpu()
+                n_ids = 2 * B * LEN                 # int64 ids counted in int32 words
+                got = torch.empty((world, pack.numel()), dtype=torch.int32, device=pack.device) if rank == 0 else None
+                dist.gather(pack, list(got.unbind(0)) if rank == 0 else None, dst=0)
                 if rank == 0:
-                    ids, lens = all_ids, all_len
-            if rank == 0 and DIST_ON:
-                ids, lens = ids.cpu(), lens.cpu()
+                    got = got.cpu()
+                    ids = got[:, :n_ids].view(torch.int64).view(world, B, LEN)        # rank-major views of the one buffer
+                    lens = got[:, n_ids:n_ids + B]
         return ids, lens, n_dirty
 
     def fence():
