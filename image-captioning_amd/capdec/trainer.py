@@ -29,6 +29,43 @@ def captions_strided_ok(ids, tgt):
     return ids.dim() == 2 and ids.stride(1) == 1 and tgt.stride(1) == 1 and ids.stride(0) == tgt.stride(0)
 
 
+def _second_stream(dev):
+    """A stream whose kernels really run beside the current stream's.  HIP multiplexes its streams onto a few hardware
+    queues (four by default), and two streams that share one run their kernels one after the other: with an RCCL
+    process group created first, the first stream torch's pool handed out sat on the queue of the default stream, and
+    the 0.75 ms vocabulary weight gradient no longer overlapped the layers' backward (6.5 instead of 5.6 ms per
+    512-sample step).  So candidates are tried: a spin kernel on each of the two streams takes the time of one when
+    they overlap, of two when they share a queue."""
+    main = torch.cuda.current_stream(dev)
+    cycles = 200_000
+
+    def spin_ms(cand):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        a.record(main)
+        torch.cuda._sleep(cycles)
+        if cand is not None:
+            with torch.cuda.stream(cand):
+                torch.cuda._sleep(cycles)
+            main.wait_stream(cand)
+        b.record(main)
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b)
+
+    with torch.cuda.device(dev):
+        spin_ms(None)
+        alone = min(spin_ms(None), spin_ms(None))
+        best = None
+        for _ in range(8):
+            cand = torch.cuda.Stream(device=dev)
+            t = min(spin_ms(cand), spin_ms(cand))
+            if t < 1.5 * alone:
+                return cand
+            if best is None or t < best[0]:
+                best = (t, cand)
+    return best[1]
+
+
 def _head_spec(model):
     """(parts, names, dropout_first) of the model's feature head, mirroring models/modules/heads.py."""
     if hasattr(model, "fc_yolo") and hasattr(model, "fc_cnn"):
@@ -96,7 +133,7 @@ class CaptionTrainer:
         if dev.type != "cuda":
             raise RuntimeError("capdec: the trainer needs the model on the GPU (HIP); there is no CPU path")
         if self._want_side:
-            self.side_stream = torch.cuda.Stream(device=dev)
+            self.side_stream = _second_stream(dev)
         # the first step's seed comes from torch's CPU generator, so torch.manual_seed makes a run repeatable
         self.state = ops.TrainState(dev, self._lr, AG.draw_seed(), 0)
         # segments in the order the backward pass finishes them
@@ -164,13 +201,24 @@ class CaptionTrainer:
 
     def _reduce_segment(self, i, works):
         if self._reduce_on:
-            AG.join_side_stream()                      # the segment's weight gradients may still be in flight there
             a, b = self.segments[i]
+            side = self.side_stream
             try:
                 if self.host_staged:
+                    AG.join_side_stream()              # the segment's weight gradients may still be in flight there
                     h = self.flat_g[a:b].cpu()
                     dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
                     self.flat_g[a:b].copy_(h)
+                elif side is not None:
+                    # The segment's weight gradients are in flight on the side stream, its bias and LayerNorm gradients
+                    # were written on this one.  The collective is issued FROM the side stream, behind a wait for this
+                    # stream's work so far: RCCL's stream then follows both, and this stream - the input-gradient chain
+                    # of the layers still to come - is not held up behind the weight gradients (joining the streams
+                    # here instead cost 1.0 ms of a 5.5 ms step: the 0.75 ms vocabulary weight gradient no longer ran
+                    # beside the layers' backward).  The handles are waited for on this stream before Adam.
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
                 else:
                     works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             except Exception as e:

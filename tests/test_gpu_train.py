@@ -954,6 +954,36 @@ def test_ragged_self_attention_on_the_matrix_cores(B, T, H, tuning_lib):
     close(o[:live], want_o[:live].numpy(), rtol=1e-5, what="forward output vs fp64")
 
 
+def test_the_trainers_second_stream_runs_beside_the_current_one():
+    """HIP multiplexes streams onto a few hardware queues and two streams on one queue run in order; the trainer picks
+    the stream of its weight gradients by trying: a spin kernel on each of the two streams must take the time of one."""
+    from capdec import trainer
+    dev = torch.device("cuda:0")
+    held = [torch.cuda.Stream(device=dev) for _ in range(3)]           # other users of torch's stream pool
+    side = trainer._second_stream(dev)
+    main = torch.cuda.current_stream(dev)
+    assert side.cuda_stream != main.cuda_stream
+
+    def spin_ms(cand):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        a.record(main)
+        torch.cuda._sleep(400_000)
+        if cand is not None:
+            with torch.cuda.stream(cand):
+                torch.cuda._sleep(400_000)
+            main.wait_stream(cand)
+        b.record(main)
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b)
+
+    spin_ms(None)
+    alone = min(spin_ms(None) for _ in range(3))
+    both = min(spin_ms(side) for _ in range(3))
+    assert both < 1.5 * alone, (alone, both)
+    del held
+
+
 def test_checkpoint_roundtrip_resumes_training_exactly(tmp_path):
     """Save after two steps in the reference's checkpoint schema, load into a fresh model + trainer, take one more
     step on both: weights, Adam moments and step counter must carry over (dropout off, so steps are deterministic
