@@ -700,13 +700,7 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            # RCCL's kernels on a high-priority stream: those live on hardware queues of their own, so a collective never
-            # shares a queue (and with it, in-order execution) with the compute streams it is meant to overlap
-            try:
-                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, pg_options=opts)
-            except (AttributeError, TypeError):
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     def note(msg):
         if rehearsal:

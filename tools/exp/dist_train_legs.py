@@ -49,7 +49,11 @@ _CT.step = _timed
 burn = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 held = [torch.cuda.Stream(device=dev) for _ in range(burn)]          # streams taken from torch's pool before the trainer's
 for leg in range(2):
-    r = bench.train_bench(dev, 0, 1, 30, 3, fence)
+    # CAPDEC_EXP_B64=1: the 64-sample shard, replayed as a HIP graph; =seq: bench.py's order at 8 ranks (512 launched, then 64 as a graph)
+    small = os.environ.get("CAPDEC_EXP_B64") == "1" or (os.environ.get("CAPDEC_EXP_B64") == "seq" and leg == 1)
+    r = bench.train_bench(dev, 0, 1, 30, 3, fence, batch=64, graph=True) if small else bench.train_bench(dev, 0, 1, 30, 3, fence)
+    if small:
+        print("collectives inside the graph:", r["config"]["allreduces_captured_in_graph"], "segments", r["config"]["allreduce_segments"])
     print(mode, "burn", burn, "leg", leg, "%.3f ms" % r["ms_per_step"], "host, timed calls: median %.3f max %.3f ms" % (sorted(_host[-30:])[15] * 1e3, max(_host[-30:]) * 1e3), flush=True)
     del _host[:]
 if bench.DIST_ON:
