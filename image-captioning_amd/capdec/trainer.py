@@ -29,36 +29,37 @@ def captions_strided_ok(ids, tgt):
     return ids.dim() == 2 and ids.stride(1) == 1 and tgt.stride(1) == 1 and ids.stride(0) == tgt.stride(0)
 
 
-def _second_stream(dev):
-    """A stream whose kernels really run beside the current stream's.  HIP multiplexes its streams onto a few hardware
-    queues (four by default), and two streams that share one run their kernels one after the other: with an RCCL
-    process group created first, the first stream torch's pool handed out sat on the queue of the default stream, and
-    the 0.75 ms vocabulary weight gradient no longer overlapped the layers' backward (6.5 instead of 5.6 ms per
-    512-sample step).  So candidates are tried: a spin kernel on each of the two streams takes the time of one when
-    they overlap, of two when they share a queue."""
+def _second_stream(dev, others=()):
+    """A stream whose kernels really run beside the current stream's (and beside those of ``others``).  HIP multiplexes
+    its streams onto a few hardware queues (four by default), and streams that share one run their kernels one after
+    the other: with an RCCL process group created first, the first stream torch's pool handed out sat on the queue of
+    the default stream, and the 0.75 ms vocabulary weight gradient no longer overlapped the layers' backward (6.5
+    instead of 5.6 ms per 512-sample step).  So candidates are tried: one spin kernel on every stream of the set takes
+    the time of one when they all overlap, of two or more when two of them share a queue."""
     main = torch.cuda.current_stream(dev)
     cycles = 200_000
 
-    def spin_ms(cand):
+    def spin_ms(streams):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
         a.record(main)
         torch.cuda._sleep(cycles)
-        if cand is not None:
-            with torch.cuda.stream(cand):
+        for st in streams:
+            with torch.cuda.stream(st):
                 torch.cuda._sleep(cycles)
-            main.wait_stream(cand)
+        for st in streams:
+            main.wait_stream(st)
         b.record(main)
         torch.cuda.synchronize(dev)
         return a.elapsed_time(b)
 
     with torch.cuda.device(dev):
-        spin_ms(None)
-        alone = min(spin_ms(None), spin_ms(None))
+        spin_ms(())
+        alone = min(spin_ms(()), spin_ms(()))
         best = None
-        for _ in range(8):
+        for _ in range(12):
             cand = torch.cuda.Stream(device=dev)
-            t = min(spin_ms(cand), spin_ms(cand))
+            t = min(spin_ms(tuple(others) + (cand,)), spin_ms(tuple(others) + (cand,)))
             if t < 1.5 * alone:
                 return cand
             if best is None or t < best[0]:
@@ -86,8 +87,8 @@ class CaptionTrainer:
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, pad_idx=0, overlap=True,
                  skip_dead_rows=True, wgrad_stream=None, graph=False, exercise_collectives=False, graph_cache=8):
-        """overlap=True: one async all-reduce per gradient segment, issued as soon as the backward pass has enqueued
-        that segment; overlap=False: a single all-reduce of the whole flat gradient buffer after the backward pass.
+        """overlap=True: one all-reduce per gradient segment on a communication stream of its own, issued as soon as the
+        backward pass has enqueued that segment; overlap=False: a single all-reduce of the whole flat gradient buffer after the backward pass.
         skip_dead_rows: run the Transformer stack on the live prefix of every caption only (the positions from a
         caption's last counted target on feed nothing but ignored loss terms); same loss and gradients, the dropout
         masks are drawn per live row.  Applies where ``autograd.ragged_supported`` holds, else the full rows run.
@@ -105,7 +106,7 @@ class CaptionTrainer:
         get_loader.py:184, so the shape changes from batch to batch: pad or bucket the captions to few lengths, or the
         step mostly runs launch by launch); the least recently used one is dropped.
         exercise_collectives: issue every broadcast / all-reduce even in a one-rank process group (where each is the
-        identity), so that the device-collective code path -- asynchronous work handles, segment boundaries, stream
+        identity), so that the device-collective code path -- the communication stream, segment boundaries, stream
         ordering -- can run on a single GPU under RCCL."""
         self.model = model
         self.overlap = overlap
@@ -134,6 +135,10 @@ class CaptionTrainer:
             raise RuntimeError("capdec: the trainer needs the model on the GPU (HIP); there is no CPU path")
         if self._want_side:
             self.side_stream = _second_stream(dev)
+        # the gradient all-reduces of the overlapped step run on a stream of this trainer's choosing (see _reduce_segment)
+        self.comm_stream = None
+        if self.coll and not self.host_staged:
+            self.comm_stream = _second_stream(dev, (self.side_stream,) if self.side_stream is not None else ())
         # the first step's seed comes from torch's CPU generator, so torch.manual_seed makes a run repeatable
         self.state = ops.TrainState(dev, self._lr, AG.draw_seed(), 0)
         # segments in the order the backward pass finishes them
@@ -209,29 +214,32 @@ class CaptionTrainer:
                     h = self.flat_g[a:b].cpu()
                     dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
                     self.flat_g[a:b].copy_(h)
-                elif side is not None:
-                    # The segment's weight gradients are in flight on the side stream, its bias and LayerNorm gradients
-                    # were written on this one.  The collective is issued FROM the side stream, behind a wait for this
-                    # stream's work so far: RCCL's stream then follows both, and this stream - the input-gradient chain
-                    # of the layers still to come - is not held up behind the weight gradients (joining the streams
-                    # here instead cost 1.0 ms of a 5.5 ms step: the 0.75 ms vocabulary weight gradient no longer ran
-                    # beside the layers' backward).  The handles are waited for on this stream before Adam.
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
                 else:
-                    works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                    # The segment's weight gradients are in flight on the side stream, its bias and LayerNorm gradients
+                    # were written on this one.  The collective runs on a third stream that waits for both, so this
+                    # stream - the input-gradient chain of the layers still to come - is not held up behind the weight
+                    # gradients (joining the streams here instead cost 0.2 ms of a 5.6 ms step).  A collective called
+                    # with async_op=False runs on the stream that is current at the call (seen in a kernel trace of
+                    # this torch build: the copy of a one-rank all_gather lands on that stream, while async_op=True
+                    # puts it on the process group's own stream - which shared a hardware queue with the default
+                    # stream there, so the all-reduce would have run in line with the kernels it is meant to overlap).
+                    # The third stream is picked like the second: its kernels run beside those of the other two.
+                    # Before Adam this stream waits for it (_wait).
+                    comm = self.comm_stream
+                    if side is not None:
+                        comm.wait_stream(side)
+                    comm.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(comm):
+                        dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+                    works.append(comm)
             except Exception as e:
                 raise RuntimeError(f"capdec: gradient all-reduce failed on rank {dist.get_rank(self.pg)}, segment {i} "
                                    f"of {len(self.segments)} (elements {a}:{b}): {e}") from e
 
     def _wait(self, works):
-        for i, w in enumerate(works):
-            try:
-                w.wait()
-            except Exception as e:
-                raise RuntimeError(f"capdec: gradient all-reduce failed on rank {dist.get_rank(self.pg)} while waiting "
-                                   f"for segment {i} of {len(self.segments)}: {e}") from e
+        if works:
+            # every segment's all-reduce is on the one communication stream, in order: Adam follows the last of them
+            torch.cuda.current_stream().wait_stream(works[-1])
 
     # ---- per-step scalars: host shadows of the device state ---------------------------------------------
     @property
