@@ -738,7 +738,11 @@ def main():
                 got = torch.empty((world, pack.numel()), dtype=torch.int32, device=pack.device) if rank == 0 else None
                 dist.gather(pack, list(got.unbind(0)) if rank == 0 else None, dst=0)
                 if rank == 0:
-                    got = got.cpu()
+                    if not rehearsal:
+                        hgot = torch.empty(got.shape, dtype=torch.int32, pin_memory=True)
+                        hgot.copy_(got, non_blocking=True)
+                        torch.cuda.current_stream().synchronize()
+                        got = hgot
                     ids = got[:, :n_ids].view(torch.int64).view(world, B, LEN)        # rank-major views of the one buffer
                     lens = got[:, n_ids:n_ids + B]
         return ids, lens, n_dirty

@@ -154,7 +154,11 @@ def tf_greedy_ids(dec, enc, max_length, sos, eos, exact=False, no_s1_shortcut=Fa
                     if to_cpu:
                         host = to_host()
                     else:
-                        host = (None, None, dirty.cpu())
+                        # the flags alone, through pinned memory (a pageable copy is staged and waited for twice)
+                        hflags = torch.empty(dirty.shape, dtype=torch.int32, pin_memory=True)
+                        hflags.copy_(dirty, non_blocking=True)
+                        torch.cuda.current_stream(dev).synchronize()
+                        host = (None, None, hflags)
                     # (almost always no flag is set: one reduction instead of building an index list)
                     rows = torch.nonzero(host[2], as_tuple=False).flatten() if bool(host[2].any()) else None
                     n_dirty = 0 if rows is None else int(rows.numel())
