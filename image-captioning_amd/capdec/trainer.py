@@ -37,7 +37,7 @@ def _second_stream(dev, others=()):
     instead of 5.6 ms per 512-sample step).  So candidates are tried: one spin kernel on every stream of the set takes
     the time of one when they all overlap, of two or more when two of them share a queue."""
     main = torch.cuda.current_stream(dev)
-    cycles = 200_000
+    cycles = 1_000_000           # 0.43 ms on an MI355X: one spin alone 0.09 ms at 200 k cycles, 0.11 beside another, 0.18 behind it
 
     def spin_ms(streams):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -968,10 +968,10 @@ def test_the_trainers_second_stream_runs_beside_the_current_one():
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
         a.record(main)
-        torch.cuda._sleep(400_000)
+        torch.cuda._sleep(1_000_000)
         if cand is not None:
             with torch.cuda.stream(cand):
-                torch.cuda._sleep(400_000)
+                torch.cuda._sleep(1_000_000)
             main.wait_stream(cand)
         b.record(main)
         torch.cuda.synchronize(dev)
