@@ -154,6 +154,9 @@ int main() {
     EXPECT(capdec_tf_greedy_decode(&m, a, 4, 1, 51, 1, 2, 0, 0, a, 1 << 20, al, ai, ai, nullptr, nullptr), CAPDEC_EINVAL);   // max_len > max_pos
     EXPECT(capdec_tf_greedy_decode(&m, a, 4, 1, 8, 1, 2, 0, 0, a, 16, al, ai, ai, nullptr, nullptr), CAPDEC_ENOMEM);        // workspace too small
     EXPECT(capdec_tf_greedy_decode(&m, una, 4, 1, 8, 1, 2, 0, 0, a, (size_t)1 << 30, al, ai, ai, nullptr, nullptr), CAPDEC_EALIGN);
+    m.emb = una;                                                                                   // step 0's rows are read 16 bytes at a time
+    EXPECT(capdec_tf_greedy_decode(&m, a, 4, 1, 8, 1, 2, 0, 0, a, (size_t)1 << 30, al, ai, ai, nullptr, nullptr), CAPDEC_EALIGN);
+    m.emb = a;
     EXPECT(capdec_tf_beam_search(&m, a, 4, 9, 1, 8, 1, 2, 0, 8, a, 1 << 20, al, ai, a, ai, nullptr), CAPDEC_EINVAL);         // W > 8
     EXPECT(capdec_tf_beam_search(&m, a, 4, 3, 1, 8, 1, 2, 5, 3, a, 1 << 20, al, ai, a, ai, nullptr), CAPDEC_EINVAL);         // t_begin >= t_end
     EXPECT(capdec_tf_forward_logits(&m, a, nullptr, 4, 1, 8, 0, a, 1 << 20, a, nullptr), CAPDEC_EINVAL);
