@@ -29,6 +29,10 @@ def captions_strided_ok(ids, tgt):
     return ids.dim() == 2 and ids.stride(1) == 1 and tgt.stride(1) == 1 and ids.stride(0) == tgt.stride(0)
 
 
+# batch rows (samples x positions) from which a launched step puts its weight gradients on the second stream
+SIDE_STREAM_MIN_ROWS = int(os.environ.get("CAPDEC_WGRAD_STREAM_MIN_ROWS", "4096"))
+
+
 def _second_stream(dev, others=()):
     """A stream whose kernels really run beside the current stream's (and beside those of ``others``).  HIP multiplexes
     its streams onto a few hardware queues (four by default), and streams that share one run their kernels one after
@@ -271,7 +275,14 @@ class CaptionTrainer:
         # reads them in place, every other path gets packed copies
         ids, tgt = captions[:, :-1], captions[:, 1:]
         self._reduce_on = reduce_inside
-        AG.use_side_stream(self.side_stream)
+        # The second stream pays when a step's kernels are long enough for the host to stay ahead of both streams.  A
+        # launched step of few rows is bound by the host's enqueueing, and the stream switches and events of the second
+        # stream add to exactly that: 64 samples x 20 positions 2.52 ms with it against 1.64 without, 128 samples 2.55
+        # against 2.30; from 256 samples on it wins (3.32 against 3.64 ms, 512 samples 5.45 against 5.87).  A captured
+        # step keeps it at any size (replayed, 64 samples: 1.64 against 1.66 ms).
+        rows = ids.shape[0] * ids.shape[1]
+        side = self.side_stream if (rows >= SIDE_STREAM_MIN_ROWS or torch.cuda.is_current_stream_capturing()) else None
+        AG.use_side_stream(side)
         try:
             if self.rnn is not None:
                 loss = self._rnn_step(feats, ids.contiguous(), tgt.contiguous())
